@@ -1,0 +1,104 @@
+"""Pins oracle/otter_oracle.py (numpy restatement) against fixtures produced by the reference's own PyTorch
+modules (oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import otter_oracle as O
+from oracle import synth
+from tests import _golden as G
+
+TOL = 2e-4  # fp32 oracle vs fp32 torch-CPU reference (different summation orders)
+
+
+@pytest.mark.parametrize("name", ["perceiver_image", "perceiver_video"])
+def test_perceiver(name):
+    m = G.meta()[name]
+    gold = G.load(name)
+    shapes = synth.perceiver_shapes("perceiver.", m["dim"], m["depth"], num_latents=m["num_latents"],
+                                    max_num_frames=m["max_num_frames"])
+    assert sorted(shapes) == m["keys"]  # parameter-name contract
+    p = synth.state_dict_for(m["seed"], shapes)
+    x = synth.tensor(m["seed"], name + ".x", m["xshape"])
+    y, c = O.perceiver_resampler_fwd(p, "perceiver.", x)
+    assert G.rel_err(y, gold["y"]) < TOL
+    R = synth.tensor(m["seed"], name + ".R", y.shape)
+    dx, g = O.perceiver_resampler_bwd(p, "perceiver.", R, c)
+    assert G.rel_err(dx, gold["dx"]) < TOL
+    G.check_grads(gold, g, TOL)
+
+
+@pytest.mark.parametrize("name", ["xattn_base", "xattn_overflow", "xattn_nomask", "xattn_noprev", "xattn_ge"])
+def test_gated_xattn(name):
+    from oracle.gen_golden import media_locations
+
+    m = G.meta()[name]
+    gold = G.load(name)
+    p = synth.state_dict_for(m["seed"], synth.gated_xattn_shapes("blk.", m["dim"], m["dim_visual"]))
+    x = synth.tensor(m["seed"], "xattn.x", (2, m["T"], m["dim"]))
+    media = synth.tensor(m["seed"], "xattn.media", (2, m["T_img"], m["n"], m["dim_visual"]))
+    ml = None if m["loc_kind"] is None else media_locations(m["loc_kind"], 2, m["T"])
+    a, _ = O.masked_cross_attention_fwd(p, "blk.attn.", x, media, ml, m["attend_previous"], m["immediate"])
+    assert G.rel_err(a, gold["attn_y"]) < TOL
+    y, c = O.gated_xattn_block_fwd(p, "blk.", x, media, ml, m["attend_previous"], m["immediate"])
+    assert G.rel_err(y, gold["y"]) < TOL
+    R = synth.tensor(m["seed"], "xattn.R", y.shape)
+    dx, dmedia, g = O.gated_xattn_block_bwd(p, "blk.", R, c)
+    assert G.rel_err(dx, gold["dx"]) < TOL
+    assert G.rel_err(dmedia, gold["dmedia"]) < TOL
+    G.check_grads(gold, g, TOL)
+
+
+def _tiny():
+    m = G.meta()["otter_tiny"]
+    t = synth.TINY
+    shapes = synth.otter_mpt_shapes(t["n_layers"], t["d_model"], t["vocab"], t["every"], clip_layers=t["clip_layers"],
+                                    clip_inter=t["clip_inter"], image=t["image"], patch=t["patch"])
+    ref_shapes = {k: tuple(v) for k, v in m["state_dict_shapes"].items()}
+    assert {k: tuple(v) for k, v in shapes.items()} == ref_shapes  # full state-dict key/shape contract
+    p = synth.state_dict_for(m["seed"], shapes)
+    spec = O.OtterSpec(t["n_layers"], t["d_model"], t["n_heads"], t["max_seq_len"], t["every"], t["media_token_id"],
+                       t["clip_heads"], t["patch"])
+    return m, p, spec
+
+
+def test_otter_tiny_forward_backward():
+    m, p, spec = _tiny()
+    gold = G.load("otter_tiny")
+    vision_x, ids, mask, labels = synth.tiny_batch(m["seed"])
+    out = O.otter_forward(p, spec, vision_x, ids, mask, labels)
+    assert G.rel_err(out["vis"], gold["vis"]) < TOL
+    assert G.rel_err(out["logits"], gold["logits"]) < TOL
+    assert abs(float(out["loss"]) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
+    g = O.otter_backward(p, spec, out)
+    assert sorted(g) == m["trainable"]  # exactly the reference's trainable set (modeling_otter.py:897-905)
+    G.check_grads(gold, g, 5e-4)
+
+
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_otter_tiny_greedy(use_cache):
+    m, p, spec = _tiny()
+    gold = G.load("otter_tiny")
+    vision_x, ids, _, _ = synth.tiny_batch(m["seed"])
+    toks = O.greedy_decode(p, spec, vision_x, ids[:, :8], 6, use_cache=use_cache)
+    assert np.array_equal(toks, gold["greedy_cache" if use_cache else "greedy_nocache"])
+    # the two decode modes must differ in general (cached steps zero the cross-attention: SURVEY 3.2)
+    assert G.rel_err(gold["greedy_cache_last_logits"], gold["greedy_nocache_last_logits"]) > 1e-4
+
+
+def test_llama_ops():
+    m = G.meta()["llama_ops"]
+    gold = G.load("llama_ops")
+    s = m["seed"]
+    x = synth.tensor(s, "rms.x", (2, m["S"], m["D"]))
+    w = synth.tensor(s, "rms.w", (m["D"],), 0.1, 1.0)
+    y, c = O.rms_norm_fwd(x, w, 1e-6)
+    assert G.rel_err(y, gold["rms_y"]) < 1e-5
+    dx, dw = O.rms_norm_bwd(synth.tensor(s, "rms.R", y.shape), c)
+    assert G.rel_err(dx, gold["rms_dx"]) < 1e-4 and G.rel_err(dw, gold["rms_dw"]) < 1e-4
+    cos, sin = O.rope_tables(m["S"], m["d"])
+    q = synth.tensor(s, "rope.q", (2, m["H"], m["S"], m["d"])).transpose(0, 2, 1, 3)  # -> [B,S,H,d]
+    k = synth.tensor(s, "rope.k", (2, m["H"], m["S"], m["d"])).transpose(0, 2, 1, 3)
+    assert G.rel_err(O.rope_fwd(q, cos, sin).transpose(0, 2, 1, 3), gold["rope_q"]) < 1e-5
+    assert G.rel_err(O.rope_fwd(k, cos, sin).transpose(0, 2, 1, 3), gold["rope_k"]) < 1e-5
+    R = synth.tensor(s, "rope.R", (2, m["H"], m["S"], m["d"])).transpose(0, 2, 1, 3)
+    assert G.rel_err(O.rope_bwd(R, cos, sin).transpose(0, 2, 1, 3), gold["rope_dq"]) < 1e-5
