@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- image-text pairs/s of one OTTER-Image-MPT7B instruction-following TRAINING step on N MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by torch.distributed.run with
+one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env; backend "nccl" = RCCL over xGMI).  Rank 0 prints
+ONE JSON line.  A "step" = one full optimizer step on a per-GPU micro-batch of 8 (image 224x224 + 512-token prompt) pairs
+(BASELINE.json configs[1]; global batch 8*N -> configs[2] at N=8, weak scaling): CLIP ViT-L/14 forward (frozen) ->
+perceiver resampler -> 32 MPT-7B blocks with 8 gated cross-attention blocks (hand-written HIP: LayerNorm, MFMA GEMMs with
+fused GELU / tanh-gate / residual epilogues, masked cross-attention) -> tied un-embedding + CE loss -> backward (dgrad
+through the frozen decoder, full backward of perceiver + gated blocks + embeddings) -> DP gradient average -> grad-norm
+clip -> AdamW.  Nothing is skipped or cached inside the timed region.  Synthetic data, random-init weights (no network).
+
+Extra objects on the JSON line (tier brief section 4):
+  roofline     -- the dominant hand-written kernel = the bf16 MFMA GEMM at the gated-FFN shape M=B*T, N=16384, K=4096
+                  (FF1 forward, and the two backward GEMMs of the same shape); achieved = 2*M*N*K / mean launch duration
+                  measured with hipEvents on the launch stream during the timed steps (otter_prof_* in the C ABI).
+  cpu_baseline -- the numpy oracle (kind "port") timed on this host's cores on a bounded per-component sample of the
+                  same step, extrapolated by component counts (see `sample`); rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; vendor 5 PF figure is 2:1 sparse)
+
+MPT7B_TEXT = dict(architectures=["MPTForCausalLM"], d_model=4096, n_heads=32, n_layers=32, expansion_ratio=4, max_seq_len=2048,
+                  vocab_size=50432, no_bias=True, norm_type="low_precision_layernorm", use_cache=False,
+                  attn_config=dict(alibi=True, alibi_bias_max=8, attn_impl="torch", attn_type="multihead_attention"))
+CLIP_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224,
+                patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=768)
+
+
+def build_model(device, seed=0, debug_layers=0):
+    from otter_amd.configuration_otter import OtterConfig
+    from otter_amd.modeling_otter import OtterForConditionalGeneration
+
+    text, vis = dict(MPT7B_TEXT), dict(CLIP_L14)
+    if debug_layers:
+        text["n_layers"] = debug_layers
+        vis["num_hidden_layers"] = 2
+    cfg = OtterConfig(vision_config=vis, text_config=text, cross_attn_every_n_layers=4)
+    torch.manual_seed(seed)
+    with torch.device(device):
+        model = OtterForConditionalGeneration(cfg)
+    g = torch.Generator(device=device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0.0, 0.02, generator=g)
+            if name.endswith("attn_gate") or name.endswith("ff_gate"):
+                p.fill_(0.5)  # zero-init gates make the block an identity (modeling_otter.py:362,371)
+        # frozen weights live in bf16 (288 GB HBM would hold fp32 too, but bf16 halves the weight stream of the frozen
+        # GEMMs); trainable parameters keep fp32 masters, exactly like accelerate's bf16 mixed precision.
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                p.data = p.data.to(torch.bfloat16)
+    model.train()
+    return model
+
+
+def synth_batch(model, B, T, device, seed):
+    """SURVEY.md section 8d synthetic batch: BOS at 0, <image> at 1, one <answer> ... <|endofchunk|> span, labels by the
+    reference's masking() rule."""
+    from otter_amd.train import masking
+
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    vision_x = torch.randn(B, 1, 1, 3, 224, 224, generator=g).to(device)
+    ids = torch.randint(1, 50277, (B, T), generator=g)
+    tok = model.text_tokenizer
+    answer_id = tok.encode("<answer>")[-1]
+    ids[:, 0] = 0
+    ids[:, 1] = model.media_token_id
+    ids[:, T // 4] = answer_id
+    ids[:, T - 1] = model.eoc_token_id
+    labels = masking(ids, answer_id, model.eoc_token_id, 0)
+    mask = torch.ones(B, T, dtype=torch.long)
+    return vision_x, ids.to(device), mask.to(device), labels.to(device)
+
+
+def cpu_baseline(T=512):
+    """Oracle (numpy port) timed per component on one pair, extrapolated to the whole step by component counts."""
+    from oracle import otter_oracle as O
+    from oracle import synth
+
+    D, Dv, V = 4096, 1024, 50432
+    r = np.random.default_rng(0)
+
+    def rnd(*s, scale=0.02):
+        return (r.standard_normal(s, dtype=np.float32) * scale)
+
+    t = {}
+    # gated cross-attention block, 1 sample x 512 tokens, fwd + bwd
+    p = {k: rnd(*s) if len(s) == 2 else (np.ones(s, np.float32) if k.endswith("weight") else np.full(s, 0.5, np.float32))
+         for k, s in synth.gated_xattn_shapes("b.", D, Dv).items()}
+    x, media = rnd(1, T, D, scale=1.0), rnd(1, 1, 64, Dv, scale=1.0)
+    ml = np.zeros((1, T), bool)
+    ml[0, 1] = True
+    t0 = time.perf_counter()
+    y, c = O.gated_xattn_block_fwd(p, "b.", x, media, ml)
+    O.gated_xattn_block_bwd(p, "b.", y, c)
+    t["gated_block"] = time.perf_counter() - t0
+    del p, c
+    # frozen MPT block, fwd + dgrad
+    p = {k: rnd(*s) if len(s) == 2 else np.ones(s, np.float32) for k, s in synth.mpt_block_shapes("m.", D).items()}
+    bias = O.mpt_attn_bias(32, T, 2048)
+    t0 = time.perf_counter()
+    y, c, _ = O.mpt_block_fwd(p, "m.", x, 32, bias)
+    O.mpt_block_bwd_input(p, "m.", y, c)
+    t["mpt_block"] = time.perf_counter() - t0
+    del p, c
+    # perceiver resampler (6 layers), 1 image, fwd + bwd
+    p = {k: rnd(*s) if len(s) == 2 and min(s) > 64 else np.ones(s, np.float32) * 0.5
+         for k, s in synth.perceiver_shapes("p.", Dv, 6).items()}
+    feats = rnd(1, 1, 1, 256, Dv, scale=1.0)
+    t0 = time.perf_counter()
+    y, c = O.perceiver_resampler_fwd(p, "p.", feats)
+    O.perceiver_resampler_bwd(p, "p.", y, c)
+    t["perceiver"] = time.perf_counter() - t0
+    del p, c
+    # one CLIP ViT-L/14 layer on 257 tokens (forward only, frozen)
+    cp = {k: rnd(*s) if len(s) >= 2 else np.ones(s, np.float32) * 0.1 for k, s in synth.clip_shapes("v.", 1024, 1, 4096, 224, 14).items()}
+    pix = rnd(1, 3, 224, 224, scale=1.0)
+    t0 = time.perf_counter()
+    O.clip_vision_fwd(cp, "v.", pix, 16, 14)
+    t["clip_layer"] = time.perf_counter() - t0
+    del cp
+    # tied un-embedding + CE: logits fwd, dX and dW bwd on 512 tokens
+    W = rnd(V, D)
+    h = rnd(T, D, scale=1.0)
+    t0 = time.perf_counter()
+    logits = h @ W.T
+    _, dl = O.cross_entropy_rolled(logits[None], r.integers(0, V, size=(1, T)))
+    _ = dl[0] @ W
+    _ = dl[0].T @ h
+    t["unembed_loss"] = time.perf_counter() - t0
+    per_pair = 8 * t["gated_block"] + 32 * t["mpt_block"] + t["perceiver"] + 24 * t["clip_layer"] + t["unembed_loss"]
+    sample = ("numpy oracle, fp32, 1 pair (1x224^2 image + 512 tokens): timed 1 gated-xattn block fwd+bwd (%.2fs), 1 MPT block "
+              "fwd+dgrad (%.2fs), 6-layer perceiver fwd+bwd (%.2fs), 1 CLIP layer fwd (%.2fs), unembed+CE fwd+bwd (%.2fs); step "
+              "time = 8*gated + 32*mpt + perceiver + 24*clip + unembed (optimizer/all-reduce not included)"
+              % (t["gated_block"], t["mpt_block"], t["perceiver"], t["clip_layer"], t["unembed_loss"]))
+    return {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE configs[1]: 8)")
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-variant", type=int, default=0)
+    ap.add_argument("--debug-layers", type=int, default=0, help="DEBUG ONLY: shrink MPT to this many layers (not a valid bench)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from otter_amd import ops
+    from otter_amd.train import TrainStep
+
+    if args.gemm_variant:
+        ops.set_gemm_variant(args.gemm_variant)
+    model = build_model(device, seed=0, debug_layers=args.debug_layers)  # identical replica on every rank (same seed)
+    step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16)
+    B, T = args.batch, args.seq
+    batch = synth_batch(model, B, T, device, seed=1000 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = step(*batch)
+    M, N, Kd = B * T, 16384, 4096
+    ops.prof_arm_gemm(M, N, Kd, max_events=max(64, args.steps * 8 * 3 + 8))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(*batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    n_launch, gemm_ms = ops.prof_collect()
+    ops.prof_disarm()
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        pairs = B * world * args.steps
+        roof = None
+        if n_launch > 0:
+            avg_s = gemm_ms / n_launch / 1e3
+            ach = 2.0 * M * N * Kd / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256> M=%d N=%d K=%d" % (M, N, Kd), "achieved": round(ach, 1),
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
+        out = {
+            "metric": "image-text pairs/s (train step) OTTER-MPT7B, 1 img+512 tok",
+            "value": round(pairs / elapsed, 3),
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") + "OTTER-Image-MPT7B instruction-following train step, 1x224^2 image + %d tokens per pair, "
+                                   "batch %d per GPU (BASELINE configs[1]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B),
+                       "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
+            "loss": round(float(loss), 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

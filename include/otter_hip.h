@@ -1,0 +1,198 @@
+/*
+ * otter_hip.h -- C ABI of libotter_hip.so: the MI355X (gfx950) kernels of the Otter vision->language fusion hot path.
+ *
+ * The reference (Luodian/Otter) is 100% Python and has NO FFI / operator registry for this path:
+ * every entry point below replaces a run of ATen calls inside one of the reference's nn.Module.forward bodies
+ * (and their autograd backward).  The file:line each one replaces is given per function, relative to
+ * /root/reference/src/otter_ai/models/.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes; no torch / hip types in the signatures (streams travel as void*).
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates persistent memory;
+ *     scratch is passed in (`*_workspace_bytes` tells how much).
+ *   - asynchronous on the given stream (hipStream_t cast to void*; NULL = default stream); thread-safe for
+ *     distinct streams; no host synchronisation inside.
+ *   - return 0 on success, a negative otter_status on failure (never throws); otter_last_error() gives a
+ *     thread-local message.
+ *   - matrices are row-major; `ld*` / `*_stride` are ROW strides in ELEMENTS.
+ *   - dtypes: OTTER_F32 / OTTER_BF16 (bf16 = upper 16 bits of an IEEE float, round-to-nearest-even on store).
+ *     All reductions / accumulations are fp32 whatever the storage type.
+ */
+#ifndef OTTER_HIP_H
+#define OTTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTTER_ABI_VERSION 1
+
+typedef enum { OTTER_F32 = 0, OTTER_BF16 = 1 } otter_dtype;
+
+typedef enum {
+    OTTER_OK = 0,
+    OTTER_ERR_ARG = -1,      /* bad shape / dtype / null pointer */
+    OTTER_ERR_UNSUPPORTED = -2,
+    OTTER_ERR_LAUNCH = -3,   /* hipGetLastError() after the launch */
+    OTTER_ERR_WORKSPACE = -4
+} otter_status;
+
+int otter_abi_version(void);
+const char* otter_last_error(void);
+/* number of CUs etc. are not needed by callers; this just proves the library sees a gfx950 device. */
+int otter_device_check(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LayerNorm / RMSNorm.  Replaces nn.LayerNorm at otter/modeling_otter.py:136-137,144,211,253,365 (perceiver +
+ * gated cross-attention), LPLayerNorm at mpt/norm.py:16-45 (beta == NULL: MPT-7B has no_bias) and LlamaRMSNorm at
+ * /root/reference/xformers_model/llama.py:95-112.
+ *
+ * Row map: output row of input row r is  (r / grp_rows) * grp_stride + row_off + (r % grp_rows)  when
+ * grp_rows > 0, else r.  It lets the perceiver write norm_media(x) and norm_latents(latents) straight into
+ * the [x ; latents] buffer that `to_kv` consumes (modeling_otter.py:166) without a torch.cat copy.
+ * y2 (optional, may be NULL) receives the same rows again, un-mapped (dense [rows, D]).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t grp_rows;   /* 0 = identity map */
+    int64_t grp_stride; /* rows */
+    int64_t row_off;    /* rows */
+} otter_rowmap;
+
+int otter_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const void* beta, int w_dtype, void* y,
+                        int y_dtype, otter_rowmap y_map, void* y2, float* mean, float* rstd, int64_t rows, int64_t D,
+                        float eps, void* stream);
+
+/* dx = LN'(dy) (+ dres if given, same dtype as dx).  dy is read through dy_map (same convention as the forward's
+ * y_map).  dgamma/dbeta (fp32, [D]) are OVERWRITTEN (or accumulated when accumulate != 0).  ws: see
+ * otter_layernorm_bwd_workspace_bytes.  gamma may be NULL (treated as ones); dbeta may be NULL. */
+int64_t otter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D);
+int otter_layernorm_bwd(const void* dy, int dy_dtype, otter_rowmap dy_map, const void* x, int x_dtype,
+                        const void* gamma, int w_dtype, const float* mean, const float* rstd, const void* dres,
+                        void* dx, int dx_dtype, float* dgamma, float* dbeta, int accumulate, void* ws, int64_t rows,
+                        int64_t D, void* stream);
+
+/* out[c] (+)= sum_r src[map(r)][c]  (fp32 [D]).  Gradient of a broadcast embedding row: frame_embs /
+ * media_time_embs (modeling_otter.py:224-229).  ws: otter_layernorm_bwd_workspace_bytes(rows, D). */
+int otter_colsum(const void* src, int src_dtype, otter_rowmap src_map, float* out, int accumulate, void* ws, int64_t rows,
+                 int64_t D, void* stream);
+
+/* y = w * cast_to_xdtype(x * rsqrt(mean(x^2) + eps))   (HF LlamaRMSNorm rounding order) */
+int otter_rmsnorm_fwd(const void* x, int x_dtype, const void* w, int w_dtype, void* y, float* rstd, int64_t rows,
+                      int64_t D, float eps, void* stream);
+int otter_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd,
+                      void* dx, float* dw, int accumulate, void* ws, int64_t rows, int64_t D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue( A[M,K] . B[N,K]^T )  -- both operands K-contiguous ("NT": exactly nn.Linear).
+ * Replaces every bias-free nn.Linear on the path (modeling_otter.py:139-141,145,147,255-257,366,368) with the
+ * element-wise tail that follows it fused into the epilogue:
+ *   OTTER_EPI_STORE     C = s * acc                      (s = tanh(*gate) if gate else 1; accumulate: C += ...)
+ *   OTTER_EPI_GELU      C = gelu_erf(acc); C2 = acc       (Linear -> nn.GELU, :366-367 / :145-146; C2 optional)
+ *   OTTER_EPI_SCALE_RES C = acc * s + R                  (x = attn(...) * attn_gate.tanh() + x, :380-393;
+ *                                                          gate == NULL gives the perceiver's plain residual :180,184)
+ *   OTTER_EPI_GATE_BWD  C = s * acc * f'(aux);  partial[block] = sum(acc * f(aux))
+ *                       f = identity (aux_is_gelu_input == 0) or gelu_erf (aux_is_gelu_input != 0).
+ *                       This is the dgrad GEMM of a gated branch: it yields d(branch input) and, through the
+ *                       deterministic two-stage reduction otter_reduce_partials, the gradient of the scalar gate.
+ * A/B are both ab_dtype.  bf16 operands run on MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate); f32 operands
+ * run on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32) -- the parity mode.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef enum { OTTER_EPI_STORE = 0, OTTER_EPI_GELU = 1, OTTER_EPI_SCALE_RES = 2, OTTER_EPI_GATE_BWD = 3 } otter_epilogue;
+
+typedef struct {
+    int kind;            /* otter_epilogue */
+    int accumulate;      /* STORE only, C must be f32 */
+    const float* gate;   /* device scalar (pre-tanh) or NULL */
+    const void* R;       /* SCALE_RES residual [M,N] */
+    int64_t ldr;
+    int r_dtype;
+    void* C2;            /* GELU: pre-activation copy (same dtype as C) or NULL */
+    int64_t ldc2;
+    const void* aux;     /* GATE_BWD */
+    int64_t ldaux;
+    int aux_dtype;
+    int aux_is_gelu_input;
+    float* partial;      /* GATE_BWD: [otter_gemm_num_partials(M,N)] floats, or NULL */
+} otter_epilogue_args;
+
+int64_t otter_gemm_num_partials(int64_t M, int64_t N, int ab_dtype);
+int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
+                  int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream);
+/* selects the bf16 kernel schedule: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 register-staged,
+ * 3 = 256x256 direct-to-LDS (global_load_lds).  Process-wide; for A/B measurements. */
+int otter_gemm_set_variant(int variant);
+
+/* out[0] (op) = scale(gate) * sum(partial[0..n))   with scale = (1 - tanh(*gate)^2) when gate != NULL.
+ * accumulate != 0 adds into out[0].  Deterministic (single block, fixed order). */
+int otter_reduce_partials(const float* partial, int64_t n, const float* gate, float* out, int accumulate, void* stream);
+
+/* dst[c][r] = src[r][c]  (+ optional same-layout cast copy dst_same[r][c]).  Used for the weight shadows
+ * (fp32 master -> bf16 W and bf16 W^T) and for the activation transposes the wgrad GEMMs need. */
+int otter_transpose(const void* src, int64_t ld_src, int src_dtype, void* dst_t, int64_t ld_dst_t, void* dst_same,
+                    int64_t ld_dst_same, int dst_dtype, int64_t rows, int64_t cols, void* stream);
+int otter_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * text_time: cumulative count of <image> tokens per text position, plus the attend_previous=False rewrite.
+ * Replaces modeling_otter.py:298-311.  media_locations: uint8/bool [B,T]; text_time: int32 [B,T].
+ * ------------------------------------------------------------------------------------------------------- */
+int otter_text_time(const uint8_t* media_locations, int32_t* text_time, int64_t B, int64_t T, int attend_previous,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Attention core (head_dim = 64 only -- the reference hard-codes dim_head=64 for both users):
+ *   perceiver latent cross-attention  modeling_otter.py:168-179   (mask_mode NONE, Tq = 64 latents, M = n1+64)
+ *   masked cross-attention            modeling_otter.py:290-333   (mask_mode EQ / GE with text_time)
+ * q [B,Tq,H*64] (row stride q_stride), k/v [B,M,H*64] (row stride kv_stride; k and v usually point into one
+ * to_kv output buffer), o like q.  sim = scale * q.k ; masked entries := -FLT_MAX ; softmax ; rows with
+ * text_time == 0 are zeroed when mask_mode == EQ (only_attend_immediate_media) ; rows whose every key is masked
+ * come out uniform (1/M) exactly as the reference's masked_fill(-finfo.max) + amax does.
+ * media index of key j is j / n_per_media.  lse [B,H,Tq] fp32 is saved for the backward.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef enum { OTTER_MASK_NONE = 0, OTTER_MASK_EQ = 1, OTTER_MASK_GE = 2 } otter_mask_mode;
+
+int otter_attn_fwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t kv_stride, void* o,
+                   int64_t o_stride, float* lse, const int32_t* text_time, int64_t B, int64_t H, int64_t Tq, int64_t M,
+                   int64_t n_per_media, int mask_mode, float scale, int dtype, void* stream);
+
+int64_t otter_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t M);
+/* dq like q; dk/dv like k/v (stride dkv_stride).  ws from otter_attn_bwd_workspace_bytes. */
+int otter_attn_bwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t kv_stride, const void* o,
+                   const void* d_o, int64_t o_stride, const float* lse, const int32_t* text_time, void* dq,
+                   int64_t dq_stride, void* dk, void* dv, int64_t dkv_stride, void* ws, int64_t B, int64_t H,
+                   int64_t Tq, int64_t M, int64_t n_per_media, int mask_mode, float scale, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * RoPE, half-split (non-interleaved) layout, optional partial rotary.  Replaces
+ * /root/reference/xformers_model/llama.py:158-166 (config C4) and flash_attn apply_rotary_emb at
+ * fuyu/modeling_persimmon.py:303-304 (config C5).  x [B,S,H,d]; cos/sin fp32 [S, rot_dim]; in place allowed.
+ * inverse != 0 applies the transpose rotation (= the backward).
+ * ------------------------------------------------------------------------------------------------------- */
+int otter_rope(const void* x, void* y, const float* cos_t, const float* sin_t, int64_t B, int64_t S, int64_t H,
+               int64_t d, int64_t rot_dim, int inverse, int dtype, void* stream);
+
+/* x[i] += y[i] for a broadcast row block:  x [groups, rows, D] += emb [rows_e .. broadcast]; used for
+ * frame_embs (modeling_otter.py:224-226).  x viewed as [outer, F, inner, D]; emb [F, D] fp32 master. */
+int otter_add_frame_embs(void* x, int x_dtype, const float* emb, int64_t outer, int64_t F, int64_t inner, int64_t D,
+                         void* stream);
+
+/* dst[r] += src[map(r)] for r in [0, rows): the perceiver backward sums the two gradient paths of
+ * norm_latents(latents) -- through to_q and through the latent rows of the [x ; latents] to_kv input
+ * (modeling_otter.py:165-167) -- without materialising a gathered copy. */
+int otter_add_rows(void* dst, const void* src, otter_rowmap src_map, int64_t rows, int64_t D, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Profiling hook used by bench.py for the `roofline` object: when enabled, every launch of the bf16 GEMM whose
+ * (M,N,K) equals the armed shape is bracketed by hipEvents on the launch stream; otter_prof_collect waits for
+ * them and returns count and total milliseconds.
+ * ------------------------------------------------------------------------------------------------------- */
+int otter_prof_arm_gemm(int64_t M, int64_t N, int64_t K, int max_events);
+int otter_prof_disarm(void);
+int otter_prof_collect(int* count, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTTER_HIP_H */

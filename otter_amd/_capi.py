@@ -1,0 +1,136 @@
+"""ctypes binding of libotter_hip.so (include/otter_hip.h).  No fallback: if the library is missing or a call fails,
+this raises -- the product path never silently degrades to PyTorch ops or to the CPU oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libotter_hip.so")
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_GELU, EPI_SCALE_RES, EPI_GATE_BWD = 0, 1, 2, 3
+MASK_NONE, MASK_EQ, MASK_GE = 0, 1, 2
+
+
+class RowMap(C.Structure):
+    _fields_ = [("grp_rows", C.c_int64), ("grp_stride", C.c_int64), ("row_off", C.c_int64)]
+
+
+class EpilogueArgs(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int),
+        ("accumulate", C.c_int),
+        ("gate", C.c_void_p),
+        ("R", C.c_void_p),
+        ("ldr", C.c_int64),
+        ("r_dtype", C.c_int),
+        ("C2", C.c_void_p),
+        ("ldc2", C.c_int64),
+        ("aux", C.c_void_p),
+        ("ldaux", C.c_int64),
+        ("aux_dtype", C.c_int),
+        ("aux_is_gelu_input", C.c_int),
+        ("partial", C.c_void_p),
+    ]
+
+
+_i64, _int, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes): exactly the declarations of include/otter_hip.h (tests/test_capi_symbols.py checks this)
+SIGNATURES = {
+    "otter_abi_version": (_int, []),
+    "otter_last_error": (C.c_char_p, []),
+    "otter_device_check": (_int, []),
+    "otter_layernorm_fwd": (_int, [_vp, _int, _vp, _vp, _int, _vp, _int, RowMap, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
+    "otter_layernorm_bwd_workspace_bytes": (_i64, [_i64, _i64]),
+    "otter_layernorm_bwd": (_int, [_vp, _int, RowMap, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _vp,
+                                   _i64, _i64, _vp]),
+    "otter_colsum": (_int, [_vp, _int, RowMap, _vp, _int, _vp, _i64, _i64, _vp]),
+    "otter_rmsnorm_fwd": (_int, [_vp, _int, _vp, _int, _vp, _vp, _i64, _i64, _f32, _vp]),
+    "otter_rmsnorm_bwd": (_int, [_vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _i64, _i64, _vp]),
+    "otter_gemm_num_partials": (_i64, [_i64, _i64, _int]),
+    "otter_gemm_nt": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _int, C.POINTER(EpilogueArgs), _vp]),
+    "otter_gemm_set_variant": (_int, [_int]),
+    "otter_reduce_partials": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
+    "otter_transpose": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _i64, _int, _i64, _i64, _vp]),
+    "otter_cast": (_int, [_vp, _int, _vp, _int, _i64, _vp]),
+    "otter_text_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
+    "otter_attn_fwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _f32, _int,
+                              _vp]),
+    "otter_attn_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
+    "otter_attn_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64,
+                              _i64, _i64, _i64, _int, _f32, _int, _vp]),
+    "otter_rope": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
+    "otter_add_frame_embs": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "otter_add_rows": (_int, [_vp, _vp, RowMap, _i64, _i64, _int, _vp]),
+    "otter_prof_arm_gemm": (_int, [_i64, _i64, _i64, _int]),
+    "otter_prof_disarm": (_int, []),
+    "otter_prof_collect": (_int, [C.POINTER(_int), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class OtterHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the C-ABI library.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OtterHipError(
+            f"{LIB_PATH} is missing: build it with `python -m otter_amd.build` (hipcc --offload-arch=gfx950). "
+            "otter_amd has no PyTorch/CPU fallback for the fusion hot path.")
+    l = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if l.otter_abi_version() != 1:
+        raise OtterHipError("libotter_hip.so ABI version mismatch; rebuild")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().otter_last_error().decode(errors="replace")
+        raise OtterHipError(f"{what or 'otter_hip'} failed ({rc}): {msg}")
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise OtterHipError(f"unsupported dtype {t.dtype} (f32 / bf16 only)")
+
+
+def dt_of(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise OtterHipError(f"unsupported dtype {dtype} (f32 / bf16 only)")
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    """The raw hipStream_t of torch's current stream: every kernel is enqueued there, so torch ops and ours interleave
+    in program order without extra synchronisation."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise OtterHipError("otter_amd kernels run on the GPU only (tensor is on %s); there is no CPU fallback" % t.device)

@@ -1,0 +1,62 @@
+"""Build libotter_hip.so (gfx950 only) in-tree with hipcc.  `python -m otter_amd.build [--force]`.
+
+The .so is git-ignored but travels with the gpurun snapshot; the product refuses to run without it (no fallback)."""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libotter_hip.so")
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "otter_hip.h")]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    if not force and _newer(LIB, srcs + hdrs):
+        return LIB
+    cc = hipcc()
+    objs = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES]
+
+    def one(pair):
+        src, obj = pair
+        if not force and _newer(obj, [src] + hdrs):
+            return obj
+        cmd = [cc, *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(one, zip(srcs, objs)))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

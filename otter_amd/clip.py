@@ -1,0 +1,117 @@
+"""Frozen producer of the fusion path: CLIP ViT vision tower -> last_hidden_state [N, 1+v, D].
+
+The reference instantiates transformers==4.35.1 `CLIPVisionModel` (modeling_otter.py:768,991; in-repo restatement at
+/root/reference/xformers_model/clip.py:50-199,393-446).  The tower is frozen and inference-only in the Otter recipe
+("next" tier), so round 1 keeps its GEMMs/attention on PyTorch-ROCm; this class exists to
+pin the *checkpoint contract*: state-dict keys are `vision_model.embeddings.*`, `vision_model.pre_layrnorm.*`,
+`vision_model.encoder.layers.{i}.*`, `vision_model.post_layernorm.*` exactly as the pinned transformers version spells
+them (transformers 5.x renamed them, which would break every published Otter checkpoint).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        D = cfg.hidden_size
+        self.class_embedding = nn.Parameter(torch.randn(D))
+        self.patch_embedding = nn.Conv2d(cfg.num_channels, D, kernel_size=cfg.patch_size, stride=cfg.patch_size, bias=False)
+        self.num_positions = (cfg.image_size // cfg.patch_size) ** 2 + 1
+        self.position_embedding = nn.Embedding(self.num_positions, D)
+
+    def forward(self, pixel_values):
+        N = pixel_values.shape[0]
+        w = self.patch_embedding.weight
+        pe = F.conv2d(pixel_values.to(w.dtype), w, stride=self.patch_embedding.stride)
+        pe = pe.flatten(2).transpose(1, 2)
+        cls = self.class_embedding.to(pe.dtype).expand(N, 1, -1)
+        return torch.cat([cls, pe], dim=1) + self.position_embedding.weight.to(pe.dtype)
+
+
+class _Attention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        D = cfg.hidden_size
+        self.num_heads = cfg.num_attention_heads
+        self.q_proj, self.k_proj = nn.Linear(D, D), nn.Linear(D, D)
+        self.v_proj, self.out_proj = nn.Linear(D, D), nn.Linear(D, D)
+
+    def forward(self, x):
+        N, S, D = x.shape
+        H = self.num_heads
+        q = self.q_proj(x).view(N, S, H, D // H).transpose(1, 2)
+        k = self.k_proj(x).view(N, S, H, D // H).transpose(1, 2)
+        v = self.v_proj(x).view(N, S, H, D // H).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)
+        return self.out_proj(o.transpose(1, 2).reshape(N, S, D))
+
+
+class _MLP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.fc1 = nn.Linear(cfg.hidden_size, cfg.intermediate_size)
+        self.fc2 = nn.Linear(cfg.intermediate_size, cfg.hidden_size)
+        self.act = cfg.hidden_act
+
+    def forward(self, x):
+        x = self.fc1(x)
+        if self.act == "quick_gelu":
+            x = x * torch.sigmoid(1.702 * x)
+        elif self.act == "gelu":
+            x = F.gelu(x)
+        else:
+            raise NotImplementedError(self.act)
+        return self.fc2(x)
+
+
+class _Layer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self_attn = _Attention(cfg)
+        self.layer_norm1 = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.mlp = _MLP(cfg)
+        self.layer_norm2 = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+    def forward(self, x):
+        x = x + self.self_attn(self.layer_norm1(x))
+        return x + self.mlp(self.layer_norm2(x))
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layers = nn.ModuleList([_Layer(cfg) for _ in range(cfg.num_hidden_layers)])
+
+
+class _VisionTransformer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.embeddings = _Embeddings(cfg)
+        self.pre_layrnorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)  # (sic) the HF attribute name
+        self.encoder = _Encoder(cfg)
+        self.post_layernorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+    def forward(self, pixel_values):
+        x = self.pre_layrnorm(self.embeddings(pixel_values))
+        for layer in self.encoder.layers:
+            x = layer(x)
+        return x  # last_hidden_state: post_layernorm applies to the pooled CLS only (clip.py:434-436)
+
+
+class CLIPVisionModel(nn.Module):
+    """`vision_encoder(x)[0]` is last_hidden_state, as the reference uses it (modeling_otter.py:991)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.vision_model = _VisionTransformer(config)
+        self.output_tokens = False
+
+    def forward(self, pixel_values):
+        h = self.vision_model(pixel_values)
+        pooled = self.vision_model.post_layernorm(h[:, 0, :])
+        return (h, pooled)

@@ -1,0 +1,114 @@
+// common.h -- shared device/host helpers for libotter_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/otter_hip.h"
+
+#define OTTER_WAVE 64
+
+// ---- error plumbing (thread-local message, negative status codes; nothing throws across the C ABI) ----
+extern thread_local char g_otter_err[512];
+#define OTTER_FAIL(code, ...)                                   \
+    do {                                                        \
+        snprintf(g_otter_err, sizeof(g_otter_err), __VA_ARGS__); \
+        return (code);                                          \
+    } while (0)
+#define OTTER_REQUIRE(cond, ...)                         \
+    do {                                                 \
+        if (!(cond)) OTTER_FAIL(OTTER_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+#define OTTER_CHECK_LAUNCH(name)                                                              \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) OTTER_FAIL(OTTER_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+__host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- bf16 <-> f32 (bf16 stored as uint16_t: upper half of an IEEE float, RNE on store) ----
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// scalar typed access through a runtime dtype tag (used only on cold / tail paths)
+__device__ __forceinline__ float ld_as_f32(const void* p, int64_t i, int dtype) {
+    return dtype == OTTER_BF16 ? bf2f(((const bf16_t*)p)[i]) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_from_f32(void* p, int64_t i, int dtype, float v) {
+    if (dtype == OTTER_BF16) ((bf16_t*)p)[i] = f2bf(v);
+    else ((float*)p)[i] = v;
+}
+
+// 8 consecutive elements -> 8 floats.  bf16: one 16-B load; f32: two 16-B loads.  p must be 16-B aligned (bf16)
+// or 16-B aligned (f32) at element index i (i multiple of 8 and row strides multiples of 8 guarantee it).
+template <typename T>
+struct Vec8;
+template <>
+struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        uint4 r = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        uint4 r;
+        r.x = pack2bf(v[0], v[1]);
+        r.y = pack2bf(v[2], v[3]);
+        r.z = pack2bf(v[4], v[5]);
+        r.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<uint4*>(p) = r;
+    }
+};
+template <>
+struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        float4 a = *reinterpret_cast<const float4*>(p);
+        float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+
+// ---- wave64 reductions (butterfly over all 64 lanes; every lane gets the result) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU() default, approximate='none')
+__device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float u) {
+    const float cdf = 0.5f * (1.0f + erff(u * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+
+__host__ __device__ __forceinline__ int64_t map_row(int64_t r, otter_rowmap m) {
+    return m.grp_rows > 0 ? (r / m.grp_rows) * m.grp_stride + m.row_off + (r % m.grp_rows) : r;
+}
+
+static inline size_t dtype_size(int dt) { return dt == OTTER_BF16 ? 2 : 4; }

@@ -1,0 +1,195 @@
+// elementwise.hip -- HBM-bound helpers: transpose(+cast), cast, RoPE, frame-embedding add.
+#include "common.h"
+
+namespace {
+
+// dst_t[c][r] = src[r][c] (and optionally dst_same[r][c] = src[r][c]) with dtype conversion.  64x64 tiles through LDS.
+template <typename S, typename D>
+__device__ __forceinline__ D cvt(S v);
+template <> __device__ __forceinline__ float cvt<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t cvt<float, bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ float cvt<bf16_t, float>(bf16_t v) { return bf2f(v); }
+template <> __device__ __forceinline__ bf16_t cvt<bf16_t, bf16_t>(bf16_t v) { return v; }
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ src, int64_t ld_src, D* __restrict__ dst_t,
+                                                        int64_t ld_dst_t, D* __restrict__ dst_same, int64_t ld_dst_same,
+                                                        int64_t rows, int64_t cols) {
+    __shared__ D tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t r = r0 + ty + 4 * k, c = c0 + tx;
+        if (r < rows && c < cols) {
+            const D v = cvt<S, D>(src[r * ld_src + c]);
+            tile[ty + 4 * k][tx] = v;
+            if (dst_same) dst_same[r * ld_dst_same + c] = v;
+        }
+    }
+    __syncthreads();
+    if (dst_t) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t c = c0 + ty + 4 * k, r = r0 + tx;
+            if (r < rows && c < cols) dst_t[c * ld_dst_t + r] = tile[tx][ty + 4 * k];
+        }
+    }
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        float v[8];
+        Vec8<S>::load(src + i, v);
+        Vec8<D>::store(dst + i, v);
+    } else {
+        for (int64_t j = i; j < n; ++j) dst[j] = cvt<S, D>(src[j]);
+    }
+}
+
+template <typename T>
+__global__ void rope_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ cs, const float* __restrict__ sn,
+                            int64_t S, int64_t H, int d, int rot, int inverse, int64_t total) {
+    // one thread per (b, s, h, p) with p in [0, d/2): handles the rotary pair (p, p + rot/2) when p < rot/2 and the
+    // two pass-through elements otherwise (laid out so that every element of the head is written exactly once).
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int half = rot / 2, hd2 = d / 2;
+    const int p = (int)(t % hd2);
+    const int64_t bsh = t / hd2;
+    const int64_t s = (bsh / H) % S;
+    const T* xp = x + bsh * d;
+    T* yp = y + bsh * d;
+    if (p < half) {
+        const float x1 = cvt<T, float>(xp[p]), x2 = cvt<T, float>(xp[p + half]);
+        const float c1 = cs[s * rot + p], c2 = cs[s * rot + p + half];
+        const float s1 = sn[s * rot + p], s2 = sn[s * rot + p + half];
+        float y1, y2;
+        if (!inverse) {
+            y1 = x1 * c1 - x2 * s1;  // x*cos + rotate_half(x)*sin, rotate_half = cat(-x2, x1)
+            y2 = x2 * c2 + x1 * s2;
+        } else {
+            y1 = x1 * c1 + x2 * s2;
+            y2 = x2 * c2 - x1 * s1;
+        }
+        yp[p] = cvt<float, T>(y1);
+        yp[p + half] = cvt<float, T>(y2);
+    } else {
+        // pass-through region [rot, d): 2*(hd2 - half) elements, two per remaining thread
+        const int e = rot + 2 * (p - half);
+        yp[e] = xp[e];
+        yp[e + 1] = xp[e + 1];
+    }
+}
+
+template <typename T>
+__global__ void add_frame_embs_kernel(T* __restrict__ x, const float* __restrict__ emb, int64_t F, int64_t inner, int64_t D,
+                                      int64_t nchunks) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const int64_t per_row = D / 8;
+    const int64_t row = c / per_row;
+    const int col = (int)(c % per_row) * 8;
+    const int64_t f = (row / inner) % F;
+    float v[8], e[8];
+    Vec8<T>::load(x + row * D + col, v);
+    Vec8<float>::load(emb + f * D + col, e);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += e[i];
+    Vec8<T>::store(x + row * D + col, v);
+}
+
+template <typename T>
+__global__ void add_rows_kernel(T* __restrict__ dst, const T* __restrict__ src, otter_rowmap map, int64_t D, int64_t nchunks) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const int64_t per_row = D / 8;
+    const int64_t row = c / per_row;
+    const int col = (int)(c % per_row) * 8;
+    float a[8], b[8];
+    Vec8<T>::load(dst + row * D + col, a);
+    Vec8<T>::load(src + map_row(row, map) * D + col, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] += b[i];
+    Vec8<T>::store(dst + row * D + col, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+int otter_add_rows(void* dst, const void* src, otter_rowmap src_map, int64_t rows, int64_t D, int dtype, void* stream) {
+    OTTER_REQUIRE(dst && src && rows > 0 && D % 8 == 0, "add_rows: bad args");
+    const int64_t nchunks = rows * (D / 8);
+    dim3 grid((unsigned)cdiv64(nchunks, 256)), block(256);
+    if (dtype == OTTER_BF16)
+        hipLaunchKernelGGL((add_rows_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, src_map, D, nchunks);
+    else
+        hipLaunchKernelGGL((add_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)dst, (const float*)src, src_map, D, nchunks);
+    OTTER_CHECK_LAUNCH("add_rows");
+    return OTTER_OK;
+}
+
+int otter_transpose(const void* src, int64_t ld_src, int src_dtype, void* dst_t, int64_t ld_dst_t, void* dst_same,
+                    int64_t ld_dst_same, int dst_dtype, int64_t rows, int64_t cols, void* stream) {
+    OTTER_REQUIRE(src && (dst_t || dst_same) && rows > 0 && cols > 0, "transpose: bad args");
+    dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64)), block(256);
+    OTTER_REQUIRE(grid.y <= 65535, "transpose: too many row tiles");
+    hipStream_t st = (hipStream_t)stream;
+#define L(S, D) hipLaunchKernelGGL((transpose_kernel<S, D>), grid, block, 0, st, (const S*)src, ld_src, (D*)dst_t, ld_dst_t, (D*)dst_same, ld_dst_same, rows, cols)
+    if (src_dtype == OTTER_F32 && dst_dtype == OTTER_F32) L(float, float);
+    else if (src_dtype == OTTER_F32 && dst_dtype == OTTER_BF16) L(float, bf16_t);
+    else if (src_dtype == OTTER_BF16 && dst_dtype == OTTER_F32) L(bf16_t, float);
+    else L(bf16_t, bf16_t);
+#undef L
+    OTTER_CHECK_LAUNCH("transpose");
+    return OTTER_OK;
+}
+
+int otter_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+    OTTER_REQUIRE(src && dst && n > 0, "cast: bad args");
+    OTTER_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "cast: 16-byte alignment");
+    dim3 grid((unsigned)cdiv64(cdiv64(n, 8), 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define L(S, D) hipLaunchKernelGGL((cast_kernel<S, D>), grid, block, 0, st, (const S*)src, (D*)dst, n)
+    if (src_dtype == OTTER_F32 && dst_dtype == OTTER_F32) L(float, float);
+    else if (src_dtype == OTTER_F32 && dst_dtype == OTTER_BF16) L(float, bf16_t);
+    else if (src_dtype == OTTER_BF16 && dst_dtype == OTTER_F32) L(bf16_t, float);
+    else L(bf16_t, bf16_t);
+#undef L
+    OTTER_CHECK_LAUNCH("cast");
+    return OTTER_OK;
+}
+
+int otter_rope(const void* x, void* y, const float* cos_t, const float* sin_t, int64_t B, int64_t S, int64_t H, int64_t d,
+               int64_t rot_dim, int inverse, int dtype, void* stream) {
+    OTTER_REQUIRE(x && y && cos_t && sin_t, "rope: null pointer");
+    OTTER_REQUIRE(d % 2 == 0 && rot_dim % 2 == 0 && rot_dim <= d && rot_dim > 0, "rope: bad head dims d=%ld rot=%ld", (long)d,
+                  (long)rot_dim);
+    const int64_t total = B * S * H * (d / 2);
+    dim3 grid((unsigned)cdiv64(total, 256)), block(256);
+    if (dtype == OTTER_BF16)
+        hipLaunchKernelGGL((rope_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, cos_t, sin_t, S,
+                           H, (int)d, (int)rot_dim, inverse, total);
+    else
+        hipLaunchKernelGGL((rope_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, cos_t, sin_t, S, H,
+                           (int)d, (int)rot_dim, inverse, total);
+    OTTER_CHECK_LAUNCH("rope");
+    return OTTER_OK;
+}
+
+int otter_add_frame_embs(void* x, int x_dtype, const float* emb, int64_t outer, int64_t F, int64_t inner, int64_t D, void* stream) {
+    OTTER_REQUIRE(x && emb && D % 8 == 0, "add_frame_embs: bad args");
+    const int64_t nchunks = outer * F * inner * (D / 8);
+    dim3 grid((unsigned)cdiv64(nchunks, 256)), block(256);
+    if (x_dtype == OTTER_BF16)
+        hipLaunchKernelGGL((add_frame_embs_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, (bf16_t*)x, emb, F, inner, D, nchunks);
+    else
+        hipLaunchKernelGGL((add_frame_embs_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)x, emb, F, inner, D, nchunks);
+    OTTER_CHECK_LAUNCH("add_frame_embs");
+    return OTTER_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,583 @@
+// gemm.hip -- C[M,N] = epilogue(A[M,K] . B[N,K]^T) on gfx950 MFMA, plus the small helpers around it.
+//
+// bf16 kernel (the MFMA-bound kernel of the path: the gated cross-attention FFN is 96.8 % of a block's FLOPs):
+//   * block tile BM x BN x 64, WM x WN waves; each wave owns a (BM/WM) x (BN/WN) sub-tile as MI x NI blocks of
+//     32x32 accumulated by v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+//   * operands are fed SWAPPED (a-operand = B rows, b-operand = A rows) so that a lane's 16 accumulator registers
+//     hold, for ONE output row m, four runs of 4 consecutive n: the epilogue then reads/writes 8-byte (bf16) or
+//     16-byte (f32) vectors of C / residual / aux instead of 2-byte scalars.
+//   * LDS image per operand tile: [rows][64] bf16 = 128 B rows, 16-B slot index XOR-swizzled with (row>>1)&7, so a
+//     ds_read_b128 lane group (16 lanes = 16 distinct rows, one k-slot) touches 16 distinct 16-B slots of the two
+//     256-B bank rows -> conflict-free (MI355X guide, LDS section).
+//   * double-buffered LDS, ONE barrier per K-tile: global loads for tile t+1 are issued before the MFMAs of tile t
+//     and written to the other buffer after them (register staging), or -- variant 3 -- go straight to LDS with
+//     global_load_lds_dwordx4 (the swizzle then lives on the per-lane SOURCE address; LDS destination is lane-linear).
+//   * XCD-aware block order: consecutive (swizzled) ids sweep M inside one N panel, and each XCD gets a contiguous
+//     chunk of that order, so a weight panel is fetched into one XCD's L2 once.
+// f32 kernel (parity mode, exact f32): v_mfma_f32_32x32x2_f32, 64x64x32 tile, padded LDS rows.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+thread_local char g_otter_err[512] = {0};
+
+namespace {
+
+struct GemmArgs {
+    const void* A; int64_t lda;
+    const void* B; int64_t ldb;
+    void* C; int64_t ldc; int cdt;
+    int64_t M, N, K;
+    int kind, accumulate;
+    const float* gate;
+    const void* R; int64_t ldr; int rdt;
+    void* C2; int64_t ldc2;
+    const void* aux; int64_t ldaux; int auxdt; int aux_gelu;
+    float* partial;
+    int gm, gn;
+};
+
+__device__ __forceinline__ void load4(const void* p, int64_t idx, int dt, float (&v)[4]) {
+    if (dt == OTTER_BF16) {
+        const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)p + idx);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    } else {
+        const float4 r = *reinterpret_cast<const float4*>((const float*)p + idx);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+}
+__device__ __forceinline__ void store4(void* p, int64_t idx, int dt, const float (&v)[4]) {
+    if (dt == OTTER_BF16) {
+        uint2 r;
+        r.x = pack2bf(v[0], v[1]);
+        r.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>((bf16_t*)p + idx) = r;
+    } else {
+        *reinterpret_cast<float4*>((float*)p + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// epilogue on 4 consecutive output columns of row m; returns this thread's contribution to the gate partial
+__device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m, int64_t n, float (&v)[4]) {
+    float part = 0.f;
+    float o[4];
+    switch (g.kind) {
+        case OTTER_EPI_STORE: {
+            if (g.accumulate) {
+                float c[4];
+                load4(g.C, m * g.ldc + n, g.cdt, c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = c[i] + s * v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = s * v[i];
+            }
+            store4(g.C, m * g.ldc + n, g.cdt, o);
+            break;
+        }
+        case OTTER_EPI_GELU: {
+            if (g.C2) store4(g.C2, m * g.ldc2 + n, g.cdt, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = gelu_erf(v[i]);
+            store4(g.C, m * g.ldc + n, g.cdt, o);
+            break;
+        }
+        case OTTER_EPI_SCALE_RES: {
+            float r[4];
+            load4(g.R, m * g.ldr + n, g.rdt, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = v[i] * s + r[i];
+            store4(g.C, m * g.ldc + n, g.cdt, o);
+            break;
+        }
+        default: {  // OTTER_EPI_GATE_BWD
+            float a[4];
+            load4(g.aux, m * g.ldaux + n, g.auxdt, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (g.aux_gelu) {
+                    part += v[i] * gelu_erf(a[i]);
+                    o[i] = s * v[i] * gelu_erf_grad(a[i]);
+                } else {
+                    part += v[i] * a[i];
+                    o[i] = s * v[i];
+                }
+            }
+            store4(g.C, m * g.ldc + n, g.cdt, o);
+            break;
+        }
+    }
+    return part;
+}
+
+// Epilogue of one 32x32 accumulator block that the owning wave has parked in LDS as [32 rows m][EPI_LD] fp32.
+// Read-back is row-major: lane l handles row (l>>3) + 8*it, columns 4*(l&7)..+3, so 8 lanes cover one 128-B (f32)
+// / 64-B (bf16) run of an output row.  Kept out of line: the accumulator registers are indexed statically by the
+// caller's fully unrolled (mi, ni) loop while everything here may use run-time indices -- inlining 8 copies of the
+// erf-heavy switch made the unroller give up and demoted the accumulators to scratch.
+constexpr int EPI_LD = 36;  // floats per parked row (32 + 4 pad: 16-B aligned rows, 4-row bank skew)
+
+__device__ __noinline__ float epilogue_block(const GemmArgs& g, float s, const float* __restrict__ blk, int64_t m_base,
+                                             int64_t n_base, int lane) {
+    float part = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        const int r = (lane >> 3) + 8 * it;
+        const int c = (lane & 7) * 4;
+        const int64_t m = m_base + r, n = n_base + c;
+        if (m < g.M && n < g.N) {
+            const float4 t = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
+            float v[4] = {t.x, t.y, t.z, t.w};
+            part += epilogue4(g, s, m, n, v);
+        }
+    }
+    return part;
+}
+
+// park one accumulator block: lane holds row m = lane&31, columns 8*grp + 4*(lane>>5) + 0..3
+__device__ __forceinline__ void park_block(float* __restrict__ blk, const f32x16_t& a, int lane) {
+    float* row = blk + (lane & 31) * EPI_LD + 4 * (lane >> 5);
+#pragma unroll
+    for (int grp = 0; grp < 4; ++grp)
+        *reinterpret_cast<float4*>(row + 8 * grp) = make_float4(a[4 * grp + 0], a[4 * grp + 1], a[4 * grp + 2], a[4 * grp + 3]);
+}
+
+// deterministic block reduction of the per-thread partial into partial[blockIdx.x]
+template <int NWAVES>
+__device__ __forceinline__ void block_partial(const GemmArgs& g, float part, float* red /* LDS, >= NWAVES floats */) {
+    if (g.kind != OTTER_EPI_GATE_BWD || g.partial == nullptr) return;
+    part = wave_sum(part);
+    __syncthreads();  // everyone is done with the LDS that `red` aliases
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVES; ++w) t += red[w];
+        g.partial[blockIdx.x] = t;
+    }
+}
+
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tile_m, int& tile_n) {
+    // bijective XCD-chunked order (blocks are dispatched round-robin over the 8 XCDs: block b -> XCD b % 8)
+    const int nwg = g.gm * g.gn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tile_m = swz % g.gm;
+    tile_n = swz / g.gm;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool GLDS>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/threads mismatch");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int tile_m, tile_n;
+    tile_of_block(g, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
+    const int64_t K = g.K;
+    const int nk = (int)((K + 63) >> 6);
+
+    // per-thread chunk coordinates (constant over the K loop)
+    const bf16_t* pa[A_CH];
+    const bf16_t* pb[B_CH];
+    int la[A_CH], lb[B_CH], ka[A_CH], kb[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+        const int slot = GLDS ? (phys ^ ((row >> 1) & 7)) : phys;        // logical k-slot this lane fetches
+        const int dst = GLDS ? phys : (phys ^ ((row >> 1) & 7));        // physical slot it lands in
+        int64_t gr = m0 + row;
+        if (gr > g.M - 1) gr = g.M - 1;
+        pa[i] = A + gr * g.lda + slot * 8;
+        ka[i] = slot * 8;
+        la[i] = row * 128 + dst * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+        const int slot = GLDS ? (phys ^ ((row >> 1) & 7)) : phys;
+        const int dst = GLDS ? phys : (phys ^ ((row >> 1) & 7));
+        int64_t gr = n0 + row;
+        if (gr > g.N - 1) gr = g.N - 1;
+        pb[i] = B + gr * g.ldb + slot * 8;
+        kb[i] = slot * 8;
+        lb[i] = BM * 128 + row * 128 + dst * 16;
+    }
+
+    f32x16_t acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const char* At = smem + buf * TILE_BYTES;
+        const char* Bt = At + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = 2 * ks + (lane >> 5);
+            bf16x8_t fa[NI], fb[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int row = wn * TN + ni * 32 + (lane & 31);
+                fa[ni] = *reinterpret_cast<const bf16x8_t*>(Bt + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wm * TM + mi * 32 + (lane & 31);
+                fb[mi] = *reinterpret_cast<const bf16x8_t*>(At + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ni], fb[mi], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    if constexpr (GLDS) {
+        // direct global -> LDS (wave-uniform LDS base + lane*16); requires K % 64 == 0 (checked on the host)
+        auto stage = [&](int buf, int kt) {
+            const int64_t koff = (int64_t)kt * 64;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) {
+                const int wbase = buf * TILE_BYTES + (i * NT + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + koff),
+                                                 (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) {
+                const int wbase = buf * TILE_BYTES + BM * 128 + (i * NT + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + koff),
+                                                 (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+            }
+        };
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) stage(cur ^ 1, t + 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        uint4 ra[A_CH], rb[B_CH];
+        auto gload = [&](int kt) {
+            const int64_t koff = (int64_t)kt * 64;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i)
+                ra[i] = (koff + ka[i] < K) ? *reinterpret_cast<const uint4*>(pa[i] + koff) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i)
+                rb[i] = (koff + kb[i] < K) ? *reinterpret_cast<const uint4*>(pb[i] + koff) : make_uint4(0, 0, 0, 0);
+        };
+        auto lstore = [&](int buf) {
+            char* base = smem + buf * TILE_BYTES;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) *reinterpret_cast<uint4*>(base + la[i]) = ra[i];
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(base + lb[i]) = rb[i];
+        };
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nk) gload(t + 1);   // in flight under the MFMAs below
+            compute(cur);
+            if (t + 1 < nk) lstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: accumulators -> wave-private LDS block -> row-major read-back + fused tail ----
+    // (the last K-loop barrier has already retired every read of the operand tiles this aliases)
+    const float s = g.gate ? tanhf(*g.gate) : 1.0f;
+    float part = 0.f;
+    float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            park_block(blk, acc[mi][ni], lane);
+            __syncthreads();
+            part += epilogue_block(g, s, blk, m0 + wm * TM + mi * 32, n0 + wn * TN + ni * 32, lane);
+            __syncthreads();
+        }
+    }
+    block_partial<WM * WN>(g, part, reinterpret_cast<float*>(smem));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// exact-f32 MFMA kernel (parity mode): 64x64x32 tile, 4 waves (2x2), one 32x32 accumulator block per wave
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = 32, LD = BK + 1;
+    __shared__ __attribute__((aligned(16))) float sm[4 * 32 * EPI_LD > (BM + BN) * LD ? 4 * 32 * EPI_LD : (BM + BN) * LD];
+    float* As = sm;
+    float* Bs = sm + BM * LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block(g, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const float* __restrict__ A = (const float*)g.A;
+    const float* __restrict__ B = (const float*)g.B;
+    const int64_t K = g.K;
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int64_t k0 = 0; k0 < K; k0 += BK) {
+        // 64 rows x 32 floats = 512 float4 chunks per operand; 2 per thread
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * 256 + tid, row = c >> 3, q = c & 7;
+            const int64_t k = k0 + q * 4;
+            int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
+            int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
+            float4 va = make_float4(0, 0, 0, 0), vb = make_float4(0, 0, 0, 0);
+            if (k < K) {  // K % 4 == 0 is enforced on the host
+                va = *reinterpret_cast<const float4*>(A + ga * g.lda + k);
+                vb = *reinterpret_cast<const float4*>(B + gb * g.ldb + k);
+            }
+            float* da = As + row * LD + q * 4;
+            float* db = Bs + row * LD + q * 4;
+            da[0] = va.x; da[1] = va.y; da[2] = va.z; da[3] = va.w;
+            db[0] = vb.x; db[1] = vb.y; db[2] = vb.z; db[3] = vb.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = Bs[(wn * 32 + (lane & 31)) * LD + kk + (lane >> 5)];  // a-operand = B rows (n)
+            const float b = As[(wm * 32 + (lane & 31)) * LD + kk + (lane >> 5)];  // b-operand = A rows (m)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float s = g.gate ? tanhf(*g.gate) : 1.0f;
+    float* blk = sm + wave * (32 * EPI_LD);
+    park_block(blk, acc, lane);
+    __syncthreads();
+    float part = epilogue_block(g, s, blk, m0 + wm * 32, n0 + wn * 32, lane);
+    block_partial<4>(g, part, sm);
+}
+
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_t n, const float* __restrict__ gate,
+                                       float* __restrict__ out, int accumulate) {
+    __shared__ float red[4];
+    float t = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) t += partial[i];
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = red[0] + red[1] + red[2] + red[3];
+        if (gate) {
+            const float th = tanhf(*gate);
+            s *= (1.0f - th * th);
+        }
+        out[0] = accumulate ? out[0] + s : s;
+    }
+}
+
+// ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
+int g_variant = 0;
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_F32 = 10 };
+
+int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
+    if (ab_dtype == OTTER_F32) return CFG_F32;
+    int v = g_variant;
+    if (v == 0) v = (cdiv64(M, 256) * cdiv64(N, 256) >= 192) ? CFG_256 : CFG_128;
+    if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
+    return v;
+}
+void cfg_tiles(int cfg, int& bm, int& bn) {
+    if (cfg == CFG_F32) { bm = 64; bn = 64; }
+    else if (cfg == CFG_128) { bm = 128; bn = 128; }
+    else { bm = 256; bn = 256; }
+}
+
+// ---- profiling hook (bench.py roofline object) ----
+struct Prof {
+    bool armed = false;
+    int64_t M = 0, N = 0, K = 0;
+    int max_events = 0, n = 0;
+    hipEvent_t* start = nullptr;
+    hipEvent_t* stop = nullptr;
+} g_prof;
+
+template <typename KernelT>
+int set_smem(KernelT kernel, int bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) OTTER_FAIL(OTTER_ERR_LAUNCH, "hipFuncSetAttribute(%d B LDS): %s", bytes, hipGetErrorString(e));
+    return OTTER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int otter_abi_version(void) { return OTTER_ABI_VERSION; }
+const char* otter_last_error(void) { return g_otter_err; }
+
+int otter_device_check(void) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess)
+        OTTER_FAIL(OTTER_ERR_LAUNCH, "no HIP device");
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        OTTER_FAIL(OTTER_ERR_UNSUPPORTED, "device is %s, this library is built for gfx950 only", p.gcnArchName);
+    return p.multiProcessorCount;
+}
+
+int otter_gemm_set_variant(int variant) {
+    if (variant < 0 || variant > 3) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    g_variant = variant;
+    return OTTER_OK;
+}
+
+int64_t otter_gemm_num_partials(int64_t M, int64_t N, int ab_dtype) {
+    int bm, bn;
+    cfg_tiles(pick_cfg(M, N, 64, ab_dtype), bm, bn);
+    return cdiv64(M, bm) * cdiv64(N, bn);
+}
+
+int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                  int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream) {
+    OTTER_REQUIRE(A && B && C && epi, "gemm: null pointer");
+    OTTER_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+    const int kal = ab_dtype == OTTER_BF16 ? 8 : 4;
+    OTTER_REQUIRE(K % kal == 0 && lda % kal == 0 && ldb % kal == 0, "gemm: K=%ld lda=%ld ldb=%ld must be multiples of %d",
+                  (long)K, (long)lda, (long)ldb, kal);
+    OTTER_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "gemm: N=%ld ldc=%ld must be multiples of 4", (long)N, (long)ldc);
+    OTTER_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm: 16-byte alignment");
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.cdt = c_dtype;
+    g.M = M; g.N = N; g.K = K;
+    g.kind = epi->kind; g.accumulate = epi->accumulate; g.gate = epi->gate;
+    g.R = epi->R; g.ldr = epi->ldr; g.rdt = epi->r_dtype;
+    g.C2 = epi->C2; g.ldc2 = epi->ldc2;
+    g.aux = epi->aux; g.ldaux = epi->ldaux; g.auxdt = epi->aux_dtype; g.aux_gelu = epi->aux_is_gelu_input;
+    g.partial = epi->partial;
+    switch (g.kind) {
+        case OTTER_EPI_STORE:
+            OTTER_REQUIRE(!g.accumulate || c_dtype == OTTER_F32, "gemm: accumulate needs an f32 C");
+            break;
+        case OTTER_EPI_GELU:
+            OTTER_REQUIRE(!g.C2 || g.ldc2 % 4 == 0, "gemm: ldc2 %% 4");
+            break;
+        case OTTER_EPI_SCALE_RES:
+            OTTER_REQUIRE(g.R && g.ldr % 4 == 0, "gemm: SCALE_RES needs R with ldr %% 4 == 0");
+            break;
+        case OTTER_EPI_GATE_BWD:
+            OTTER_REQUIRE(g.aux && g.ldaux % 4 == 0, "gemm: GATE_BWD needs aux with ldaux %% 4 == 0");
+            break;
+        default:
+            OTTER_FAIL(OTTER_ERR_ARG, "gemm: unknown epilogue %d", g.kind);
+    }
+    const int cfg = pick_cfg(M, N, K, ab_dtype);
+    int bm, bn;
+    cfg_tiles(cfg, bm, bn);
+    g.gm = (int)cdiv64(M, bm);
+    g.gn = (int)cdiv64(N, bn);
+    const dim3 grid((unsigned)(g.gm * g.gn));
+    hipStream_t st = (hipStream_t)stream;
+    const bool prof = g_prof.armed && g_prof.M == M && g_prof.N == N && g_prof.K == K && g_prof.n < g_prof.max_events;
+    if (prof) hipEventRecord(g_prof.start[g_prof.n], st);
+    if (cfg == CFG_F32) {
+        hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
+    } else if (cfg == CFG_128) {
+        static bool once = false;
+        const int smem = 2 * (128 + 128) * 128;
+        if (!once) { int rc = set_smem(gemm_bf16_kernel<128, 128, 2, 2, false>, smem); if (rc) return rc; once = true; }
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, false>), grid, dim3(256), smem, st, g);
+    } else if (cfg == CFG_256) {
+        static bool once = false;
+        const int smem = 2 * (256 + 256) * 128;
+        if (!once) { int rc = set_smem(gemm_bf16_kernel<256, 256, 2, 4, false>, smem); if (rc) return rc; once = true; }
+        hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, false>), grid, dim3(512), smem, st, g);
+    } else {
+        static bool once = false;
+        const int smem = 2 * (256 + 256) * 128;
+        if (!once) { int rc = set_smem(gemm_bf16_kernel<256, 256, 2, 4, true>, smem); if (rc) return rc; once = true; }
+        hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, true>), grid, dim3(512), smem, st, g);
+    }
+    if (prof) hipEventRecord(g_prof.stop[g_prof.n++], st);
+    OTTER_CHECK_LAUNCH("gemm");
+    return OTTER_OK;
+}
+
+int otter_reduce_partials(const float* partial, int64_t n, const float* gate, float* out, int accumulate, void* stream) {
+    OTTER_REQUIRE(partial && out && n > 0, "reduce_partials: bad args");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n, gate, out, accumulate);
+    OTTER_CHECK_LAUNCH("reduce_partials");
+    return OTTER_OK;
+}
+
+int otter_prof_arm_gemm(int64_t M, int64_t N, int64_t K, int max_events) {
+    otter_prof_disarm();
+    OTTER_REQUIRE(max_events > 0 && max_events <= 65536, "prof: max_events");
+    g_prof.start = new hipEvent_t[max_events];
+    g_prof.stop = new hipEvent_t[max_events];
+    for (int i = 0; i < max_events; ++i) {
+        hipEventCreate(&g_prof.start[i]);
+        hipEventCreate(&g_prof.stop[i]);
+    }
+    g_prof.M = M; g_prof.N = N; g_prof.K = K;
+    g_prof.max_events = max_events;
+    g_prof.n = 0;
+    g_prof.armed = true;
+    return OTTER_OK;
+}
+
+int otter_prof_disarm(void) {
+    if (g_prof.start) {
+        for (int i = 0; i < g_prof.max_events; ++i) {
+            hipEventDestroy(g_prof.start[i]);
+            hipEventDestroy(g_prof.stop[i]);
+        }
+        delete[] g_prof.start;
+        delete[] g_prof.stop;
+    }
+    g_prof = Prof();
+    return OTTER_OK;
+}
+
+int otter_prof_collect(int* count, double* total_ms) {
+    OTTER_REQUIRE(count && total_ms, "prof_collect: null");
+    double tot = 0.0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        hipEventSynchronize(g_prof.stop[i]);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]);
+        tot += ms;
+    }
+    *count = g_prof.n;
+    *total_ms = tot;
+    g_prof.n = 0;
+    return OTTER_OK;
+}
+
+}  // extern "C"

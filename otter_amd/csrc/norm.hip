@@ -1,0 +1,340 @@
+// norm.hip -- LayerNorm / RMSNorm forward + backward for gfx950.
+//
+// HBM-bound row kernels: one wave64 per row, the row lives in registers (8 elements = 16 B (bf16) / 32 B (f32) per
+// lane per chunk, chunk c of a row covers columns [c*512 + lane*8, +8)), two-pass statistics from registers
+// (mean, then sum (x-mean)^2 -- the same formulation as ATen's CPU layer_norm, not E[x^2]-mean^2), wave64 butterfly
+// reductions, no LDS.  Algorithmic bytes per row: D*(sizeof x + sizeof y) forward; D*(dy + x + dx) backward, plus a
+// second column-parallel pass over dy and x for dgamma/dbeta (deterministic two-stage reduction, no atomics).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void load8(const void* p, int64_t idx, int dt, float (&v)[8]) {
+    if (dt == OTTER_BF16) Vec8<bf16_t>::load((const bf16_t*)p + idx, v);
+    else Vec8<float>::load((const float*)p + idx, v);
+}
+__device__ __forceinline__ void store8(void* p, int64_t idx, int dt, const float (&v)[8]) {
+    if (dt == OTTER_BF16) Vec8<bf16_t>::store((bf16_t*)p + idx, v);
+    else Vec8<float>::store((float*)p + idx, v);
+}
+__device__ __forceinline__ float round_to(float v, int dt) { return dt == OTTER_BF16 ? bf2f(f2bf(v)) : v; }
+
+// NCH = chunks (of 512 columns) per row held by a wave; D <= NCH*512, D % 8 == 0.
+template <int NCH, bool RMS>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const void* __restrict__ x, int xdt, const void* __restrict__ gamma,
+                                                       const void* __restrict__ beta, int wdt, void* __restrict__ y, int ydt,
+                                                       otter_rowmap ymap, void* __restrict__ y2, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < D) {
+            load8(x, row * D + col, xdt, v[c]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += RMS ? v[c][i] * v[c][i] : v[c][i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    float mu = 0.f, var;
+    if (RMS) {
+        var = s / (float)D;
+    } else {
+        mu = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int col = c * 512 + lane * 8;
+            if (col < D) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = v[c][i] - mu;
+                    q += d * d;
+                }
+            }
+        }
+        var = wave_sum(q) / (float)D;
+    }
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+    const int64_t orow = map_row(row, ymap);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < D) {
+            float g[8], b[8], o[8];
+            if (gamma) load8(gamma, col, wdt, g);
+            if (beta) load8(beta, col, wdt, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = (v[c][i] - mu) * rs;
+                if (RMS) t = round_to(t, xdt);  // HF LlamaRMSNorm: weight * normalised.to(input_dtype)
+                if (gamma) t *= g[i];
+                if (beta) t += b[i];
+                o[i] = t;
+            }
+            store8(y, orow * D + col, ydt, o);
+            if (y2) store8(y2, row * D + col, ydt, o);
+        }
+    }
+}
+
+template <int NCH, bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const void* __restrict__ dy, int dydt, otter_rowmap dymap,
+                                                          const void* __restrict__ x, int xdt, const void* __restrict__ gamma,
+                                                          int wdt, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const void* __restrict__ dres, void* __restrict__ dx, int dxdt,
+                                                          int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float mu = RMS ? 0.f : mean[row];
+    const float rs = rstd[row];
+    const int64_t drow = map_row(row, dymap);
+    float xh[NCH][8], g[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < D) {
+            float xv[8], dv[8], gm[8];
+            load8(x, row * D + col, xdt, xv);
+            load8(dy, drow * D + col, dydt, dv);
+            if (gamma) load8(gamma, col, wdt, gm);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = (xv[i] - mu) * rs;
+                if (RMS) t = round_to(t, xdt);
+                xh[c][i] = t;
+                const float gg = gamma ? dv[i] * gm[i] : dv[i];
+                g[c][i] = gg;
+                s1 += gg;
+                s2 += gg * t;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xh[c][i] = g[c][i] = 0.f;
+        }
+    }
+    const float m1 = RMS ? 0.f : wave_sum(s1) / (float)D;
+    const float m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < D) {
+            float o[8], r[8];
+            if (dres) load8(dres, row * D + col, dxdt, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float t = (g[c][i] - m1 - xh[c][i] * m2) * rs;
+                if (dres) t += r[i];
+                o[i] = t;
+            }
+            store8(dx, row * D + col, dxdt, o);
+        }
+    }
+}
+
+// column-parallel partial sums for dgamma / dbeta: grid (ceil(D/512), RCH); one wave per block.
+template <bool RMS>
+__global__ __launch_bounds__(64) void norm_bwd_dw_partial_kernel(const void* __restrict__ dy, int dydt, otter_rowmap dymap,
+                                                                 const void* __restrict__ x, int xdt,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 float* __restrict__ part, int64_t rows, int D, int rch) {
+    const int lane = threadIdx.x;
+    const int col = blockIdx.x * 512 + lane * 8;
+    if (col >= D) return;
+    const int64_t per = cdiv64(rows, rch);
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+    float ag[8], ab[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ag[i] = ab[i] = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        float xv[8], dv[8];
+        load8(x, r * D + col, xdt, xv);
+        load8(dy, map_row(r, dymap) * D + col, dydt, dv);
+        const float mu = RMS ? 0.f : mean[r];
+        const float rs = rstd[r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float t = (xv[i] - mu) * rs;
+            if (RMS) t = round_to(t, xdt);
+            ag[i] += dv[i] * t;
+            ab[i] += dv[i];
+        }
+    }
+    float* pg = part + ((int64_t)blockIdx.y * 2 + 0) * D + col;
+    float* pb = part + ((int64_t)blockIdx.y * 2 + 1) * D + col;
+    Vec8<float>::store(pg, ag);
+    Vec8<float>::store(pb, ab);
+}
+
+__global__ void norm_bwd_dw_final_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                         int D, int rch, int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= D) return;
+    float sg = 0.f, sb = 0.f;
+    for (int k = 0; k < rch; ++k) {
+        sg += part[((int64_t)k * 2 + 0) * D + col];
+        sb += part[((int64_t)k * 2 + 1) * D + col];
+    }
+    if (dgamma) dgamma[col] = accumulate ? dgamma[col] + sg : sg;
+    if (dbeta) dbeta[col] = accumulate ? dbeta[col] + sb : sb;
+}
+
+// column sums of a row-mapped matrix: partial[k][col] = sum over the k-th row chunk of src[map(r)][col]
+__global__ __launch_bounds__(64) void colsum_partial_kernel(const void* __restrict__ src, int sdt, otter_rowmap map,
+                                                            float* __restrict__ part, int64_t rows, int D, int rch) {
+    const int lane = threadIdx.x;
+    const int col = blockIdx.x * 512 + lane * 8;
+    if (col >= D) return;
+    const int64_t per = cdiv64(rows, rch);
+    const int64_t r0 = (int64_t)blockIdx.y * per;
+    const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        float v[8];
+        load8(src, map_row(r, map) * D + col, sdt, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += v[i];
+    }
+    Vec8<float>::store(part + (int64_t)blockIdx.y * D + col, a);
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int D, int rch, int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= D) return;
+    float s = 0.f;
+    for (int k = 0; k < rch; ++k) s += part[(int64_t)k * D + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+int pick_nch(int64_t D) {
+    int n = 1;
+    while ((int64_t)n * 512 < D) n <<= 1;
+    return n;
+}
+int pick_rch(int64_t rows) {
+    int64_t r = rows / 32;
+    if (r < 1) r = 1;
+    if (r > 256) r = 256;
+    return (int)r;
+}
+
+template <bool RMS>
+int launch_fwd(const void* x, int xdt, const void* gamma, const void* beta, int wdt, void* y, int ydt, otter_rowmap ymap,
+               void* y2, float* mean, float* rstd, int64_t rows, int64_t D, float eps, hipStream_t st) {
+    OTTER_REQUIRE(x && y && rows > 0 && D > 0, "norm_fwd: null pointer or empty shape");
+    OTTER_REQUIRE(D % 8 == 0 && D <= 8192, "norm_fwd: D=%ld must be a multiple of 8 and <= 8192", (long)D);
+    const int nch = pick_nch(D);
+    dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+#define L(N) hipLaunchKernelGGL((norm_fwd_kernel<N, RMS>), grid, block, 0, st, x, xdt, gamma, beta, wdt, y, ydt, ymap, y2, mean, rstd, rows, (int)D, eps)
+    switch (nch) {
+        case 1: L(1); break;
+        case 2: L(2); break;
+        case 4: L(4); break;
+        case 8: L(8); break;
+        default: L(16); break;
+    }
+#undef L
+    OTTER_CHECK_LAUNCH("norm_fwd");
+    return OTTER_OK;
+}
+
+template <bool RMS>
+int launch_bwd(const void* dy, int dydt, otter_rowmap dymap, const void* x, int xdt, const void* gamma, int wdt,
+               const float* mean, const float* rstd, const void* dres, void* dx, int dxdt, float* dgamma, float* dbeta,
+               int accumulate, void* ws, int64_t rows, int64_t D, hipStream_t st) {
+    OTTER_REQUIRE(dy && x && rstd && rows > 0, "norm_bwd: null pointer or empty shape");
+    OTTER_REQUIRE(D % 8 == 0 && D <= 8192, "norm_bwd: D=%ld must be a multiple of 8 and <= 8192", (long)D);
+    const int nch = pick_nch(D);
+    if (dx) {
+        dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+#define L(N) hipLaunchKernelGGL((norm_bwd_dx_kernel<N, RMS>), grid, block, 0, st, dy, dydt, dymap, x, xdt, gamma, wdt, mean, rstd, dres, dx, dxdt, rows, (int)D)
+        switch (nch) {
+            case 1: L(1); break;
+            case 2: L(2); break;
+            case 4: L(4); break;
+            case 8: L(8); break;
+            default: L(16); break;
+        }
+#undef L
+        OTTER_CHECK_LAUNCH("norm_bwd_dx");
+    }
+    if (dgamma || dbeta) {
+        if (!ws) OTTER_FAIL(OTTER_ERR_WORKSPACE, "norm_bwd: workspace required for dgamma/dbeta");
+        const int rch = pick_rch(rows);
+        dim3 grid((unsigned)cdiv64(D, 512), (unsigned)rch), block(64);
+        hipLaunchKernelGGL((norm_bwd_dw_partial_kernel<RMS>), grid, block, 0, st, dy, dydt, dymap, x, xdt, mean, rstd, (float*)ws,
+                           rows, (int)D, rch);
+        OTTER_CHECK_LAUNCH("norm_bwd_dw_partial");
+        hipLaunchKernelGGL(norm_bwd_dw_final_kernel, dim3((unsigned)cdiv64(D, 256)), dim3(256), 0, st, (const float*)ws, dgamma,
+                           dbeta, (int)D, rch, accumulate);
+        OTTER_CHECK_LAUNCH("norm_bwd_dw_final");
+    }
+    return OTTER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int otter_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const void* beta, int w_dtype, void* y, int y_dtype,
+                        otter_rowmap y_map, void* y2, float* mean, float* rstd, int64_t rows, int64_t D, float eps,
+                        void* stream) {
+    return launch_fwd<false>(x, x_dtype, gamma, beta, w_dtype, y, y_dtype, y_map, y2, mean, rstd, rows, D, eps,
+                             (hipStream_t)stream);
+}
+
+int64_t otter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (int64_t)pick_rch(rows) * 2 * D * 4; }
+
+int otter_layernorm_bwd(const void* dy, int dy_dtype, otter_rowmap dy_map, const void* x, int x_dtype, const void* gamma,
+                        int w_dtype, const float* mean, const float* rstd, const void* dres, void* dx, int dx_dtype,
+                        float* dgamma, float* dbeta, int accumulate, void* ws, int64_t rows, int64_t D, void* stream) {
+    OTTER_REQUIRE(mean, "layernorm_bwd: mean is required");
+    return launch_bwd<false>(dy, dy_dtype, dy_map, x, x_dtype, gamma, w_dtype, mean, rstd, dres, dx, dx_dtype, dgamma, dbeta,
+                             accumulate, ws, rows, D, (hipStream_t)stream);
+}
+
+int otter_colsum(const void* src, int src_dtype, otter_rowmap src_map, float* out, int accumulate, void* ws, int64_t rows,
+                 int64_t D, void* stream) {
+    OTTER_REQUIRE(src && out && rows > 0 && D % 8 == 0, "colsum: bad args");
+    if (!ws) OTTER_FAIL(OTTER_ERR_WORKSPACE, "colsum: workspace required (otter_layernorm_bwd_workspace_bytes)");
+    const int rch = pick_rch(rows);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv64(D, 512), (unsigned)rch), dim3(64), 0, st, src, src_dtype, src_map,
+                       (float*)ws, rows, (int)D, rch);
+    OTTER_CHECK_LAUNCH("colsum_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv64(D, 256)), dim3(256), 0, st, (const float*)ws, out, (int)D, rch,
+                       accumulate);
+    OTTER_CHECK_LAUNCH("colsum_final");
+    return OTTER_OK;
+}
+
+int otter_rmsnorm_fwd(const void* x, int x_dtype, const void* w, int w_dtype, void* y, float* rstd, int64_t rows, int64_t D,
+                      float eps, void* stream) {
+    otter_rowmap id = {0, 0, 0};
+    return launch_fwd<true>(x, x_dtype, w, nullptr, w_dtype, y, x_dtype, id, nullptr, nullptr, rstd, rows, D, eps,
+                            (hipStream_t)stream);
+}
+
+int otter_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd, void* dx,
+                      float* dw, int accumulate, void* ws, int64_t rows, int64_t D, void* stream) {
+    otter_rowmap id = {0, 0, 0};
+    return launch_bwd<true>(dy, x_dtype, id, x, x_dtype, w, w_dtype, nullptr, rstd, nullptr, dx, x_dtype, dw, nullptr,
+                            accumulate, ws, rows, D, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,384 @@
+"""Autograd functions of the fusion hot path: one torch.autograd.Function per reference module forward
+(OtterPerceiverBlock, OtterGatedCrossAttentionBlock, LayerNorm), each a fixed schedule of libotter_hip.so calls with a
+hand-derived backward.  No ATen arithmetic happens here; torch supplies tensors (memory) and the autograd graph.
+
+Precision contract (mirrors what accelerate's bf16 autocast does to the reference, SURVEY.md section 7 "autocast dtype
+contract"): `cd` = compute dtype (bf16 under autocast / bf16 models, f32 otherwise) is the storage type of GEMM operands
+and intermediate activations; the residual stream keeps the dtype of the incoming hidden states; parameters keep their
+master dtype, with per-step cd shadows (W and W^T) cached on the parameter version counter; all accumulation is fp32.
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from . import ops
+from ._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE, MASK_EQ, MASK_GE, MASK_NONE, RowMap
+
+HEAD_DIM = 64
+
+
+def compute_dtype_for(x: torch.Tensor) -> torch.dtype:
+    if x.dtype == torch.bfloat16:
+        return torch.bfloat16
+    if torch.is_autocast_enabled():
+        adt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+        if adt == torch.bfloat16:
+            return torch.bfloat16
+    return torch.float32
+
+
+class _Shadows:
+    """cd-typed copies of weight matrices (same layout, and transposed for the dgrad GEMMs), refreshed when the
+    parameter's version counter moves (optimizer.step / load_state_dict bump it)."""
+
+    def __init__(self):
+        self._w = {}
+        self._wt = {}
+
+    @staticmethod
+    def _key(p, cd):
+        return (id(p), cd)
+
+    def _valid(self, store, p, cd):
+        ent = store.get(self._key(p, cd))
+        if ent is None:
+            return None
+        ref, ver, ptr_, t = ent
+        if ref() is not p or ver != p._version or ptr_ != p.data_ptr():
+            return None
+        return t
+
+    def w(self, p: torch.Tensor, cd) -> torch.Tensor:
+        if p.dtype == cd:
+            return p.detach()
+        t = self._valid(self._w, p, cd)
+        if t is None:
+            t = ops.cast(p.detach(), cd)
+            self._w[self._key(p, cd)] = (weakref.ref(p), p._version, p.data_ptr(), t)
+        return t
+
+    def wt(self, p: torch.Tensor, cd) -> torch.Tensor:
+        t = self._valid(self._wt, p, cd)
+        if t is None:
+            t = ops.transpose(p.detach(), cd)
+            self._wt[self._key(p, cd)] = (weakref.ref(p), p._version, p.data_ptr(), t)
+        return t
+
+    def clear(self):
+        self._w.clear()
+        self._wt.clear()
+
+
+shadows = _Shadows()
+
+
+def _wgrad(dyT: torch.Tensor, xT: torch.Tensor, gate=None) -> torch.Tensor:
+    """dW[out,in] = (s *) dy^T . x   from the two transposed, zero-padded operands (fp32 result)."""
+    return ops.gemm_nt(dyT, xT, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
+
+
+def _flat_gate(g):
+    if g.dtype != torch.float32:
+        raise RuntimeError("gate parameters must be fp32 (1-element) tensors")
+    return g.detach()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LayerNorm (perceiver.norm, and the frozen MPT LPLayerNorm)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        need = x.requires_grad or (weight is not None and weight.requires_grad)
+        y, mean, rstd = ops.layernorm_fwd(x2, weight.detach() if weight is not None else None,
+                                          bias.detach() if bias is not None else None, out_dtype, eps, need_stats=need)
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        ctx.shp = shp
+        ctx.xdtype = x.dtype
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        need_dw = weight is not None and weight.requires_grad
+        dy2 = dy.reshape(-1, ctx.shp[-1]).contiguous()
+        dx, dg, db = ops.layernorm_bwd(dy2, x2, weight.detach() if weight is not None else None, mean, rstd, ctx.xdtype,
+                                       need_dw=need_dw, need_dbeta=ctx.has_bias, need_dx=ctx.needs_input_grad[0])
+        return (dx.view(ctx.shp) if dx is not None else None, dg.to(weight.dtype) if dg is not None else None,
+                db.to(weight.dtype) if (db is not None and ctx.has_bias) else None, None, None)
+
+
+def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
+    return LayerNormFn.apply(x, weight, bias, eps, out_dtype or x.dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# small building blocks (stand-alone OtterMaskedCrossAttention, latent broadcast, dtype casts)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class CastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        return ops.cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.cast(dy.contiguous(), ctx.src), None
+
+
+class ExpandLatentsFn(torch.autograd.Function):
+    """latents [n, D] -> [G, n, D] (modeling_otter.py:232); backward = column sum over the G copies (HIP colsum)."""
+
+    @staticmethod
+    def forward(ctx, latents, G):
+        ctx.G = G
+        ctx.pdtype = latents.dtype
+        return latents.detach().unsqueeze(0).expand(G, -1, -1).contiguous()  # memory replication only
+
+    @staticmethod
+    def backward(ctx, dy):
+        G, n, D = dy.shape
+        g = ops.colsum(dy.contiguous().view(G, n * D), None, G).view(n, D)
+        return g.to(ctx.pdtype), None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T for a bias-free nn.Linear; x [rows, in] in the compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x2, W):
+        cd = x2.dtype
+        ctx.save_for_backward(x2, W)
+        return ops.gemm_nt(x2, shadows.w(W, cd))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        cd = x2.dtype
+        dy = dy.contiguous()
+        dx = ops.gemm_nt(dy, shadows.wt(W, cd)) if ctx.needs_input_grad[0] else None
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = _wgrad(ops.transpose(dy, cd), ops.transpose(x2, cd)).to(W.dtype)
+        return dx, dW
+
+
+class AttnCoreFn(torch.autograd.Function):
+    """o = softmax(mask(scale q k^T)) v on [B,Tq,H*64] / [B,M,2*H*64] buffers (attention core only)."""
+
+    @staticmethod
+    def forward(ctx, q3, kv3, heads, tt, n_per_media, mask_mode):
+        inner = q3.shape[-1]
+        scale = HEAD_DIM ** -0.5
+        o, lse = ops.attn_fwd(q3, kv3[..., :inner], kv3[..., inner:], heads, tt, n_per_media, mask_mode, scale)
+        ctx.save_for_backward(q3, kv3, o, lse, tt)
+        ctx.meta = (heads, n_per_media, mask_mode, scale, inner)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q3, kv3, o, lse, tt = ctx.saved_tensors
+        heads, n_per_media, mask_mode, scale, inner = ctx.meta
+        dq, dkv = ops.attn_bwd(q3, kv3[..., :inner], kv3[..., inner:], o, do.contiguous(), lse, heads, tt, n_per_media, mask_mode,
+                               scale)
+        return dq, dkv, None, None, None, None
+
+
+def masked_cross_attention(x, media, tt, mask_mode, heads, eps, norm_w, norm_b, Wq, Wkv, Wo):
+    """OtterMaskedCrossAttention.forward (modeling_otter.py:262-340) used stand-alone: returns to_out(attn) in the compute
+    dtype (bf16 under autocast, like the reference)."""
+    B, T, D = x.shape
+    _, T_img, n, Dv = media.shape
+    inner = Wq.shape[0]
+    if inner != heads * HEAD_DIM:
+        raise RuntimeError(f"masked cross-attention: inner dim {inner} != heads*64 (dim_head must be 64)")
+    cd = compute_dtype_for(x)
+    xn = layer_norm(x, norm_w, norm_b, eps, cd).reshape(B * T, D)
+    q = LinearFn.apply(xn, Wq)
+    med = CastFn.apply(media.reshape(B * T_img * n, Dv).contiguous(), cd)
+    kv = LinearFn.apply(med, Wkv)
+    o = AttnCoreFn.apply(q.view(B, T, inner), kv.view(B, T_img * n, 2 * inner), heads, tt, n, mask_mode)
+    return LinearFn.apply(o.reshape(B * T, inner), Wo).view(B, T, D)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OtterGatedCrossAttentionBlock  (otter/modeling_otter.py:262-340 + 373-395)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class GatedCrossAttentionFn(torch.autograd.Function):
+    """y = block(x, media).  Inputs: x [B,T,D]; media [B,T_img,n,Dv]; tt int32 [B,T] or None."""
+
+    @staticmethod
+    def forward(ctx, x, media, tt, mask_mode, heads, eps, norm_w, norm_b, Wq, Wkv, Wo, attn_gate, ffn_w, ffn_b, W1, W2,
+                ff_gate):
+        B, T, D = x.shape
+        _, T_img, n, Dv = media.shape
+        inner = Wq.shape[0]
+        if inner != heads * HEAD_DIM:
+            raise RuntimeError(f"gated cross-attention: inner dim {inner} != heads*64 (dim_head must be 64)")
+        cd = compute_dtype_for(x)
+        rd = x.dtype
+        N, M = B * T, T_img * n
+        x2 = x.reshape(N, D).contiguous()
+        scale = HEAD_DIM ** -0.5
+        ga, gf = _flat_gate(attn_gate), _flat_gate(ff_gate)
+        # --- masked cross attention ---
+        xn, mean1, rstd1 = ops.layernorm_fwd(x2, norm_w.detach(), norm_b.detach(), cd, eps)
+        q = ops.gemm_nt(xn, shadows.w(Wq, cd))
+        med = ops.cast(media.reshape(B * M, Dv).contiguous(), cd)
+        kv = ops.gemm_nt(med, shadows.w(Wkv, cd))                                   # [B*M, 2*inner]
+        kv3 = kv.view(B, M, 2 * inner)
+        o, lse = ops.attn_fwd(q.view(B, T, inner), kv3[..., :inner], kv3[..., inner:], heads, tt, n, mask_mode, scale)
+        o2 = o.view(N, inner)
+        x1 = ops.gemm_nt(o2, shadows.w(Wo, cd), out_dtype=rd, kind=EPI_SCALE_RES, gate=ga, R=x2)   # attn*tanh(g)+x
+        # --- gated feed-forward ---
+        f, mean2, rstd2 = ops.layernorm_fwd(x1, ffn_w.detach(), ffn_b.detach(), cd, eps)
+        need_grad = any(ctx.needs_input_grad)
+        u = torch.empty((N, W1.shape[0]), dtype=cd, device=x.device) if need_grad else None
+        h = ops.gemm_nt(f, shadows.w(W1, cd), kind=EPI_GELU, C2=u)
+        y = ops.gemm_nt(h, shadows.w(W2, cd), out_dtype=rd, kind=EPI_SCALE_RES, gate=gf, R=x1)       # ff*tanh(g)+x1
+        if need_grad:
+            ctx.save_for_backward(x2, xn, mean1, rstd1, q, kv, o2, lse, x1, mean2, rstd2, f, u, h, med, tt, norm_w, Wq, Wkv,
+                                  Wo, attn_gate, ffn_w, W1, W2, ff_gate)
+            ctx.meta = (B, T, D, T_img, n, Dv, inner, heads, mask_mode, scale, cd, rd, media.dtype)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, xn, mean1, rstd1, q, kv, o2, lse, x1, mean2, rstd2, f, u, h, med, tt, norm_w, Wq, Wkv, Wo, attn_gate, ffn_w, W1,
+         W2, ff_gate) = ctx.saved_tensors
+        B, T, D, T_img, n, Dv, inner, heads, mask_mode, scale, cd, rd, media_dtype = ctx.meta
+        N, M = B * T, T_img * n
+        dev = dy.device
+        ga, gf = _flat_gate(attn_gate), _flat_gate(ff_gate)
+        dy2 = dy.reshape(N, D).contiguous()
+        # ---- feed-forward branch:  y = (h W2^T) tanh(gf) + x1 ----
+        dyT, dy_cd = ops.transpose(dy2, cd, want_same=True)
+        part = torch.empty(ops.gemm_num_partials(N, W1.shape[0], cd), dtype=torch.float32, device=dev)
+        dU = ops.gemm_nt(dy_cd, shadows.wt(W2, cd), kind=EPI_GATE_BWD, gate=gf, aux=u, aux_gelu=True, partial=part)
+        d_ff_gate = ops.reduce_partials(part, gate=gf)
+        dW2 = _wgrad(dyT, ops.transpose(h, cd), gate=gf)
+        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd))
+        df = ops.gemm_nt(dU, shadows.wt(W1, cd))
+        dx1, dg2, db2 = ops.layernorm_bwd(df, x1, ffn_w.detach(), mean2, rstd2, rd, dres=dy2)
+        # ---- attention branch:  x1 = (o Wo^T) tanh(ga) + x ----
+        dx1T, dx1_cd = ops.transpose(dx1, cd, want_same=True)
+        part2 = torch.empty(ops.gemm_num_partials(N, inner, cd), dtype=torch.float32, device=dev)
+        dO = ops.gemm_nt(dx1_cd, shadows.wt(Wo, cd), kind=EPI_GATE_BWD, gate=ga, aux=o2, aux_gelu=False, partial=part2)
+        d_attn_gate = ops.reduce_partials(part2, gate=ga)
+        dWo = _wgrad(dx1T, ops.transpose(o2, cd), gate=ga)
+        kv3 = kv.view(B, M, 2 * inner)
+        dq, dkv = ops.attn_bwd(q.view(B, T, inner), kv3[..., :inner], kv3[..., inner:], o2.view(B, T, inner),
+                               dO.view(B, T, inner), lse, heads, tt, n, mask_mode, scale)
+        dq2, dkv2 = dq.view(N, inner), dkv.view(B * M, 2 * inner)
+        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(xn, cd))
+        dxn = ops.gemm_nt(dq2, shadows.wt(Wq, cd))
+        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(med, cd))
+        dmedia = None
+        if ctx.needs_input_grad[1]:
+            dmedia = ops.gemm_nt(dkv2, shadows.wt(Wkv, cd), out_dtype=media_dtype).view(B, T_img, n, Dv)
+        dx, dg1, db1 = ops.layernorm_bwd(dxn, x2, norm_w.detach(), mean1, rstd1, rd, dres=dx1)
+
+        def pg(g, p):
+            return g.to(p.dtype) if g.dtype != p.dtype else g
+
+        return (dx.view(B, T, D), dmedia, None, None, None, None, pg(dg1, norm_w), pg(db1, norm_w), pg(dWq, Wq), pg(dWkv, Wkv),
+                pg(dWo, Wo), pg(d_attn_gate, attn_gate), pg(dg2, ffn_w), pg(db2, ffn_w), pg(dW1, W1), pg(dW2, W2),
+                pg(d_ff_gate, ff_gate))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OtterPerceiverBlock  (otter/modeling_otter.py:151-184)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class PerceiverBlockFn(torch.autograd.Function):
+    """latents' = block(x, latents).  x [G,n1,D] media features (G = b*T), latents [G,n2,D]."""
+
+    @staticmethod
+    def forward(ctx, x, latents, heads, eps, nm_w, nm_b, nl_w, nl_b, Wq, Wkv, Wo, ff_w, ff_b, W1, W2):
+        G, n1, D = x.shape
+        n2 = latents.shape[1]
+        inner = Wq.shape[0]
+        if inner != heads * HEAD_DIM:
+            raise RuntimeError(f"perceiver: inner dim {inner} != heads*64 (dim_head must be 64)")
+        cd = compute_dtype_for(x)
+        rd = latents.dtype
+        nk = n1 + n2
+        scale = HEAD_DIM ** -0.5
+        x2 = x.reshape(G * n1, D).contiguous()
+        l2 = latents.reshape(G * n2, D).contiguous()
+        # norm_media(x) and norm_latents(latents) land directly in the [x ; latents] buffer `to_kv` reads (no torch.cat)
+        kv_in = torch.empty((G * nk, D), dtype=cd, device=x.device)
+        _, mean_m, rstd_m = ops.layernorm_fwd(x2, nm_w.detach(), nm_b.detach(), cd, eps, y=kv_in, ymap=RowMap(n1, nk, 0))
+        ln = torch.empty((G * n2, D), dtype=cd, device=x.device)
+        _, mean_l, rstd_l = ops.layernorm_fwd(l2, nl_w.detach(), nl_b.detach(), cd, eps, y=kv_in, ymap=RowMap(n2, nk, n1), y2=ln)
+        q = ops.gemm_nt(ln, shadows.w(Wq, cd))                                     # [G*n2, inner]
+        kv = ops.gemm_nt(kv_in, shadows.w(Wkv, cd))                                # [G*nk, 2*inner]
+        kv3 = kv.view(G, nk, 2 * inner)
+        o, lse = ops.attn_fwd(q.view(G, n2, inner), kv3[..., :inner], kv3[..., inner:], heads, None, 1, MASK_NONE, scale)
+        o2 = o.view(G * n2, inner)
+        out1 = ops.gemm_nt(o2, shadows.w(Wo, cd), out_dtype=rd, kind=EPI_SCALE_RES, R=l2)            # to_out + residual
+        f, mean_f, rstd_f = ops.layernorm_fwd(out1, ff_w.detach(), ff_b.detach(), cd, eps)
+        need_grad = any(ctx.needs_input_grad)
+        u = torch.empty((G * n2, W1.shape[0]), dtype=cd, device=x.device) if need_grad else None
+        h = ops.gemm_nt(f, shadows.w(W1, cd), kind=EPI_GELU, C2=u)
+        y = ops.gemm_nt(h, shadows.w(W2, cd), out_dtype=rd, kind=EPI_SCALE_RES, R=out1)              # ff + residual
+        if need_grad:
+            ctx.save_for_backward(x2, l2, kv_in, ln, mean_m, rstd_m, mean_l, rstd_l, q, kv, o2, lse, out1, mean_f, rstd_f, f, u, h,
+                                  nm_w, nl_w, Wq, Wkv, Wo, ff_w, W1, W2)
+            ctx.meta = (G, n1, n2, D, inner, heads, scale, cd, rd, x.dtype)
+        return y.view(G, n2, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2, l2, kv_in, ln, mean_m, rstd_m, mean_l, rstd_l, q, kv, o2, lse, out1, mean_f, rstd_f, f, u, h, nm_w, nl_w, Wq, Wkv, Wo,
+         ff_w, W1, W2) = ctx.saved_tensors
+        G, n1, n2, D, inner, heads, scale, cd, rd, xdtype = ctx.meta
+        nk = n1 + n2
+        dy2 = dy.reshape(G * n2, D).contiguous()
+        # feed-forward: y = gelu(f W1^T) W2^T + out1
+        dyT, dy_cd = ops.transpose(dy2, cd, want_same=True)
+        dU = ops.gemm_nt(dy_cd, shadows.wt(W2, cd), kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+        dW2 = _wgrad(dyT, ops.transpose(h, cd))
+        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd))
+        df = ops.gemm_nt(dU, shadows.wt(W1, cd))
+        dout1, dgf, dbf = ops.layernorm_bwd(df, out1, ff_w.detach(), mean_f, rstd_f, rd, dres=dy2)
+        # attention: out1 = o Wo^T + latents
+        d1T, d1_cd = ops.transpose(dout1, cd, want_same=True)
+        dO = ops.gemm_nt(d1_cd, shadows.wt(Wo, cd))
+        dWo = _wgrad(d1T, ops.transpose(o2, cd))
+        kv3 = kv.view(G, nk, 2 * inner)
+        dq, dkv = ops.attn_bwd(q.view(G, n2, inner), kv3[..., :inner], kv3[..., inner:], o2.view(G, n2, inner),
+                               dO.view(G, n2, inner), lse, heads, None, 1, MASK_NONE, scale)
+        dq2, dkv2 = dq.view(G * n2, inner), dkv.view(G * nk, 2 * inner)
+        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(ln, cd))
+        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(kv_in, cd))
+        dkv_in = ops.gemm_nt(dkv2, shadows.wt(Wkv, cd))                            # [G*nk, D] grads of [xn ; ln]
+        # d(ln) = dq Wq (through to_q) + the latent rows of dkv_in (through to_kv)
+        dln = ops.gemm_nt(dq2, shadows.wt(Wq, cd))
+        ops.add_rows_(dln, dkv_in, RowMap(n2, nk, n1))
+        dl, dgl, dbl = ops.layernorm_bwd(dln, l2, nl_w.detach(), mean_l, rstd_l, rd, dres=dout1)
+        dx = None
+        need_dx = ctx.needs_input_grad[0]
+        # norm_media backward reads its dy rows out of dkv_in through the same row map the forward wrote with
+        dxm, dgm, dbm = ops.layernorm_bwd(dkv_in, x2, nm_w.detach(), mean_m, rstd_m, xdtype, dymap=RowMap(n1, nk, 0),
+                                          need_dx=need_dx)
+        if need_dx:
+            dx = dxm.view(G, n1, D)
+
+        def pg(g, p):
+            return g.to(p.dtype) if g.dtype != p.dtype else g
+
+        return (dx, dl.view(G, n2, D), None, None, pg(dgm, nm_w), pg(dbm, nm_w), pg(dgl, nl_w), pg(dbl, nl_w), pg(dWq, Wq),
+                pg(dWkv, Wkv), pg(dWo, Wo), pg(dgf, ff_w), pg(dbf, ff_w), pg(dW1, W1), pg(dW2, W2))

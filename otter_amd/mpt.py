@@ -1,0 +1,263 @@
+"""Frozen host of the fusion path: the MPT decoder (reference: src/otter_ai/models/mpt/{modeling_mpt,blocks,attention,
+norm,custom_embedding}.py) re-stated for PyTorch-ROCm.
+
+Scope note: the decoder is *frozen* in the Otter recipe and is NOT one of the hand-written
+rows of round 1 -- its GEMMs and causal attention go through PyTorch-ROCm (hipBLASLt / SDPA), its LayerNorms through
+libotter_hip.so.  What this file must get exactly right is the contract the hot path plugs into: parameter names
+(`transformer.wte`, `transformer.blocks.{i}.{norm_1,attn.Wqkv,attn.out_proj,norm_2,ffn.up_proj,ffn.down_proj}`,
+`transformer.norm_f`), ALiBi + causal masking, the tied un-embedding, the rolled-label loss and the legacy tuple KV cache
+(k: [B,H,d,S], v: [B,H,S,d]) that `generate` relies on.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from transformers import PretrainedConfig, PreTrainedModel
+from transformers.modeling_outputs import BaseModelOutputWithPast, CausalLMOutputWithPast
+
+from . import functional as OF
+
+_ATTN_DEFAULTS = dict(attn_type="multihead_attention", attn_pdrop=0.0, attn_impl="torch", qk_ln=False, clip_qkv=None,
+                      softmax_scale=None, prefix_lm=False, attn_uses_sequence_id=False, alibi=True, alibi_bias_max=8)
+
+
+class MPTConfig(PretrainedConfig):
+    """Same fields as the reference's mpt/configuration_mpt.py:14-90 (only what OTTER-MPT7B uses is honoured)."""
+
+    model_type = "mpt"
+
+    def __init__(self, d_model=2048, n_heads=16, n_layers=24, expansion_ratio=4, max_seq_len=2048, vocab_size=50368,
+                 resid_pdrop=0.0, emb_pdrop=0.0, learned_pos_emb=True, attn_config=None, init_device="cpu", logit_scale=None,
+                 no_bias=False, verbose=0, embedding_fraction=1.0, norm_type="low_precision_layernorm", use_cache=False,
+                 init_config=None, **kwargs):
+        self.d_model, self.n_heads, self.n_layers = d_model, n_heads, n_layers
+        self.expansion_ratio, self.max_seq_len, self.vocab_size = expansion_ratio, max_seq_len, vocab_size
+        self.resid_pdrop, self.emb_pdrop, self.learned_pos_emb = resid_pdrop, emb_pdrop, learned_pos_emb
+        ac = dict(_ATTN_DEFAULTS)
+        ac.update(attn_config or {})
+        self.attn_config = ac
+        self.init_device, self.logit_scale, self.no_bias, self.verbose = init_device, logit_scale, no_bias, verbose
+        self.embedding_fraction, self.norm_type, self.use_cache = embedding_fraction, norm_type, use_cache
+        self.init_config = init_config or {}
+        kwargs.pop("tie_word_embeddings", None)
+        kwargs.setdefault("hidden_size", d_model)  # OtterLMMixin.init_otter reads config.hidden_size (modeling_otter.py:473)
+        super().__init__(tie_word_embeddings=True, **kwargs)
+        self._validate()
+
+    def _validate(self):
+        a = self.attn_config
+        if self.d_model % self.n_heads:
+            raise ValueError("d_model must be divisible by n_heads")
+        if a["attn_type"] != "multihead_attention" or a["prefix_lm"] or a["attn_uses_sequence_id"] or a["qk_ln"] or a["clip_qkv"]:
+            raise NotImplementedError("otter_amd's MPT host implements the OTTER-MPT7B attention configuration only "
+                                      "(multihead, causal, no qk_ln / clip_qkv / prefix_lm / sequence_id)")
+        if not a["alibi"]:
+            raise NotImplementedError("learned position embeddings (alibi=False) are not implemented")
+        if self.norm_type not in ("low_precision_layernorm", "layernorm"):
+            raise NotImplementedError(f"norm_type {self.norm_type}")
+
+
+def alibi_slopes(n_heads: int, alibi_bias_max: int = 8) -> torch.Tensor:
+    """mpt/attention.py:447-455."""
+    _n = 2 ** math.ceil(math.log2(n_heads))
+    m = torch.arange(1, _n + 1, dtype=torch.float32) * (alibi_bias_max / _n)
+    slopes = 1.0 / torch.pow(2, m)
+    if _n != n_heads:
+        slopes = torch.cat([slopes[1::2], slopes[::2]])[:n_heads]
+    return slopes
+
+
+class SharedEmbedding(nn.Embedding):
+    """mpt/custom_embedding.py:7-11."""
+
+    def forward(self, input: torch.Tensor, unembed: bool = False) -> torch.Tensor:
+        if unembed:
+            return F.linear(input, self.weight.to(input.dtype))
+        return super().forward(input)
+
+
+class _Norm(nn.LayerNorm):
+    """LPLayerNorm (mpt/norm.py:16-45) on the HIP LayerNorm kernel: statistics in fp32, output in the compute dtype."""
+
+    def forward(self, x):
+        return OF.layer_norm(x, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
+
+
+class MPTMLP(nn.Module):
+    def __init__(self, d_model, expansion_ratio, bias):
+        super().__init__()
+        self.up_proj = nn.Linear(d_model, expansion_ratio * d_model, bias=bias)
+        self.act = nn.GELU()
+        self.down_proj = nn.Linear(expansion_ratio * d_model, d_model, bias=bias)
+
+    def forward(self, x):
+        return self.down_proj(self.act(self.up_proj(x)))
+
+
+class MultiheadAttention(nn.Module):
+    def __init__(self, d_model, n_heads, bias):
+        super().__init__()
+        self.d_model, self.n_heads = d_model, n_heads
+        self.softmax_scale = 1.0 / math.sqrt(d_model / n_heads)
+        self.Wqkv = nn.Linear(d_model, 3 * d_model, bias=bias)
+        self.out_proj = nn.Linear(d_model, d_model, bias=bias)
+
+    def forward(self, x, past_key_value=None, attn_bias=None, is_causal=True):
+        B, S, D = x.shape
+        H, d = self.n_heads, D // self.n_heads
+        q, k, v = self.Wqkv(x).chunk(3, dim=2)
+        q = q.view(B, S, H, d).transpose(1, 2)  # [B,H,S,d]
+        k = k.view(B, S, H, d).transpose(1, 2)
+        v = v.view(B, S, H, d).transpose(1, 2)
+        if past_key_value is not None:
+            if len(past_key_value) != 0:
+                k = torch.cat([past_key_value[0].transpose(2, 3), k], dim=2)
+                v = torch.cat([past_key_value[1], v], dim=2)
+            past_key_value = (k.transpose(2, 3), v)  # reference layout: k [B,H,d,S], v [B,H,S,d]
+        if attn_bias is not None and attn_bias.size(0) == 1 and B > 1:
+            attn_bias = attn_bias.expand(B, -1, -1, -1)
+        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias, dropout_p=0.0, is_causal=False, scale=self.softmax_scale)
+        ctx = ctx.transpose(1, 2).reshape(B, S, D)
+        return self.out_proj(ctx), past_key_value
+
+
+class MPTBlock(nn.Module):
+    """mpt/blocks.py:23-88."""
+
+    def __init__(self, config: MPTConfig):
+        super().__init__()
+        bias = not config.no_bias
+        self.norm_1 = _Norm(config.d_model, bias=bias)
+        self.attn = MultiheadAttention(config.d_model, config.n_heads, bias)
+        self.norm_2 = _Norm(config.d_model, bias=bias)
+        self.ffn = MPTMLP(config.d_model, config.expansion_ratio, bias)
+
+    def forward(self, x, past_key_value=None, attn_bias=None, attention_mask=None, is_causal=True):
+        a = self.norm_1(x)
+        b, past_key_value = self.attn(a, past_key_value=past_key_value, attn_bias=attn_bias, is_causal=is_causal)
+        x = x + b
+        m = self.norm_2(x)
+        x = x + self.ffn(m)
+        return x, None, past_key_value
+
+
+class MPTPreTrainedModel(PreTrainedModel):
+    config_class = MPTConfig
+    base_model_prefix = "model"
+    _no_split_modules = ["MPTBlock"]
+
+    def _init_weights(self, module):
+        std = self.config.init_config.get("init_std", 0.02) if isinstance(self.config.init_config, dict) else 0.02
+        if isinstance(module, nn.Linear):
+            nn.init.normal_(module.weight, 0.0, std)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.Embedding):
+            nn.init.normal_(module.weight, 0.0, std)
+        elif isinstance(module, nn.LayerNorm):
+            nn.init.ones_(module.weight)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+
+
+class MPTModel(MPTPreTrainedModel):
+    def __init__(self, config: MPTConfig):
+        super().__init__(config)
+        self.alibi_bias_max = config.attn_config["alibi_bias_max"]
+        self.wte = SharedEmbedding(config.vocab_size, config.d_model)
+        self.blocks = nn.ModuleList([MPTBlock(config) for _ in range(config.n_layers)])
+        self.norm_f = _Norm(config.d_model, bias=not config.no_bias)
+        self.is_causal = True
+        self._slopes = None
+
+    def get_input_embeddings(self):
+        return self.wte
+
+    def set_input_embeddings(self, value):
+        self.wte = value
+
+    def _attn_bias(self, s_k: int, device, attention_mask: Optional[torch.Tensor]):
+        """[1 or B, H, 1, s_k] fp32 = ALiBi (key-position form, attention.py:458-464) + padding (modeling_mpt.py:135-144)."""
+        if self._slopes is None or self._slopes.device != device:
+            self._slopes = alibi_slopes(self.config.n_heads, self.alibi_bias_max).to(device)
+        pos = torch.arange(1 - s_k, 1, dtype=torch.float32, device=device)
+        bias = pos.view(1, 1, 1, s_k) * self._slopes.view(1, -1, 1, 1)
+        if attention_mask is not None:
+            am = attention_mask.bool()[:, -s_k:]
+            if not bool(am.all()):
+                bias = bias.masked_fill(~am.view(-1, 1, 1, s_k), torch.finfo(torch.float32).min)
+        return bias
+
+    def forward(self, input_ids, past_key_values=None, attention_mask=None, use_cache=None, return_dict=True, **unused):
+        use_cache = use_cache if use_cache is not None else self.config.use_cache
+        if attention_mask is not None and self.training and int(attention_mask[:, 0].sum()) != attention_mask.shape[0]:
+            raise NotImplementedError("MPT does not support training with left padding.")
+        S = input_ids.size(1)
+        if S > self.config.max_seq_len:
+            raise ValueError(f"Cannot forward input with seq_len={S}, this model only supports seq_len<={self.config.max_seq_len}")
+        x = self.wte(input_ids)
+        s_past = 0
+        if past_key_values is not None and len(past_key_values) and len(past_key_values[0]) != 0:
+            s_past = past_key_values[0][0].size(3)
+        # one additive mask per forward, shared by every block: ALiBi (+ padding) and, for S > 1, the causal triangle
+        s_k = S + s_past
+        attn_bias = self._attn_bias(s_k, x.device, attention_mask)
+        if self.is_causal and S != 1:
+            causal = torch.ones(S, s_k, dtype=torch.bool, device=x.device).tril(diagonal=s_k - S)
+            attn_bias = attn_bias.expand(-1, -1, S, -1).masked_fill(~causal, torch.finfo(torch.float32).min)
+        attn_bias = attn_bias.to(OF.compute_dtype_for(x))
+        if use_cache and past_key_values is None:
+            past_key_values = [() for _ in range(self.config.n_layers)]
+        for i, block in enumerate(self.blocks):
+            pkv = past_key_values[i] if past_key_values is not None else None
+            x, _, pkv = block(x, past_key_value=pkv, attn_bias=attn_bias, attention_mask=None, is_causal=self.is_causal)
+            if past_key_values is not None:
+                past_key_values[i] = pkv
+        x = self.norm_f(x)
+        return BaseModelOutputWithPast(last_hidden_state=x, past_key_values=past_key_values)
+
+
+class MPTForCausalLM(MPTPreTrainedModel):
+    def __init__(self, config: MPTConfig):
+        super().__init__(config)
+        self.transformer = MPTModel(config)
+        self.logit_scale = None
+        if config.logit_scale is not None:
+            ls = config.logit_scale
+            self.logit_scale = 1 / math.sqrt(config.d_model) if ls == "inv_sqrt_d_model" else ls
+
+    def get_input_embeddings(self):
+        return self.transformer.wte
+
+    def set_input_embeddings(self, value):
+        self.transformer.wte = value
+
+    def get_output_embeddings(self):
+        return self.transformer.wte
+
+    def set_output_embeddings(self, new_embeddings):
+        self.transformer.wte = new_embeddings
+
+    def get_decoder(self):
+        return self.transformer
+
+    def set_decoder(self, decoder):
+        self.transformer = decoder
+
+    def forward(self, input_ids, past_key_values=None, attention_mask=None, labels=None, use_cache=None, return_dict=True,
+                **unused):
+        out = self.transformer(input_ids=input_ids, past_key_values=past_key_values, attention_mask=attention_mask,
+                               use_cache=use_cache)
+        logits = self.transformer.wte(out.last_hidden_state, True)
+        if self.logit_scale is not None:
+            logits = logits * self.logit_scale
+        loss = None
+        if labels is not None:
+            _labels = torch.roll(labels, shifts=-1)      # flat roll, exactly as modeling_mpt.py:428-435
+            _labels[:, -1] = -100
+            loss = F.cross_entropy(logits.view(-1, logits.size(-1)).float(), _labels.to(logits.device).view(-1))
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=out.past_key_values)

@@ -1,0 +1,299 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/otter_hip.h).
+
+PyTorch is used here for device memory (torch.empty), the current HIP stream and nothing else: all arithmetic
+happens in libotter_hip.so.  Every wrapper validates devices/dtypes/contiguity and raises on error."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _capi as K
+from ._capi import BF16, EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE, F32, MASK_EQ, MASK_GE, MASK_NONE, RowMap
+
+_IDENT = RowMap(0, 0, 0)
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device (stream-ordered reuse: everything runs on torch's current stream)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        b = self.bufs.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.bufs[key] = b
+        return b
+
+
+_ws = _Workspace()
+
+
+def _c2d(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise K.OtterHipError(f"expected a row-major 2-D tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# norms
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def layernorm_fwd(x2d, gamma, beta, out_dtype, eps=1e-5, y=None, ymap: Optional[RowMap] = None, y2=None, need_stats=True):
+    """x2d [rows, D] contiguous.  Returns (y, mean, rstd)."""
+    K.require_cuda(x2d, gamma, beta)
+    x2d = _c2d(x2d)
+    assert x2d.is_contiguous()
+    rows, D = x2d.shape
+    if y is None:
+        y = torch.empty((rows, D), dtype=out_dtype, device=x2d.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device) if need_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device) if need_stats else None
+    wdt = K.dt(gamma) if gamma is not None else F32
+    if gamma is not None and beta is not None and gamma.dtype != beta.dtype:
+        raise K.OtterHipError("layernorm: gamma/beta dtype mismatch")
+    K.check(K.lib().otter_layernorm_fwd(x2d.data_ptr(), K.dt(x2d), K.ptr(gamma), K.ptr(beta), wdt, y.data_ptr(), K.dt(y),
+                                        ymap or _IDENT, K.ptr(y2), K.ptr(mean), K.ptr(rstd), rows, D, float(eps), K.stream()),
+            "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x2d, gamma, mean, rstd, dx_dtype, dres=None, dymap: Optional[RowMap] = None, need_dw=True,
+                  need_dbeta=True, need_dx=True):
+    """Returns (dx, dgamma, dbeta) -- dgamma/dbeta fp32."""
+    K.require_cuda(dy, x2d)
+    rows, D = x2d.shape
+    dev = x2d.device
+    dx = torch.empty((rows, D), dtype=dx_dtype, device=dev) if need_dx else None
+    if dres is not None and dres.dtype != dx_dtype:
+        raise K.OtterHipError("layernorm_bwd: dres must have the dx dtype")
+    dg = torch.empty(D, dtype=torch.float32, device=dev) if need_dw else None
+    db = torch.empty(D, dtype=torch.float32, device=dev) if (need_dw and need_dbeta) else None
+    ws = None
+    if need_dw:
+        ws = _ws.get(K.lib().otter_layernorm_bwd_workspace_bytes(rows, D), dev)
+    wdt = K.dt(gamma) if gamma is not None else F32
+    K.check(K.lib().otter_layernorm_bwd(dy.data_ptr(), K.dt(dy), dymap or _IDENT, x2d.data_ptr(), K.dt(x2d), K.ptr(gamma), wdt,
+                                        mean.data_ptr(), rstd.data_ptr(), K.ptr(dres), K.ptr(dx), K.dt_of(dx_dtype), K.ptr(dg),
+                                        K.ptr(db), 0, K.ptr(ws), rows, D, K.stream()), "layernorm_bwd")
+    return dx, dg, db
+
+
+def colsum(src2d, src_map: Optional[RowMap], rows: int, out=None, accumulate=False):
+    """out[c] (+)= sum over r < rows of src2d[map(r)][c]; fp32 [D]."""
+    D = src2d.shape[1]
+    if out is None:
+        out = torch.empty(D, dtype=torch.float32, device=src2d.device)
+    ws = _ws.get(K.lib().otter_layernorm_bwd_workspace_bytes(rows, D), src2d.device)
+    K.check(K.lib().otter_colsum(src2d.data_ptr(), K.dt(src2d), src_map or _IDENT, out.data_ptr(), 1 if accumulate else 0,
+                                 ws.data_ptr(), rows, D, K.stream()), "colsum")
+    return out
+
+
+def rmsnorm_fwd(x2d, w, eps=1e-6):
+    K.require_cuda(x2d, w)
+    rows, D = x2d.shape
+    y = torch.empty_like(x2d)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    K.check(K.lib().otter_rmsnorm_fwd(x2d.data_ptr(), K.dt(x2d), w.data_ptr(), K.dt(w), y.data_ptr(), rstd.data_ptr(), rows, D,
+                                      float(eps), K.stream()), "rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x2d, w, rstd):
+    rows, D = x2d.shape
+    dx = torch.empty_like(x2d)
+    dw = torch.empty(D, dtype=torch.float32, device=x2d.device)
+    ws = _ws.get(K.lib().otter_layernorm_bwd_workspace_bytes(rows, D), x2d.device)
+    K.check(K.lib().otter_rmsnorm_bwd(dy.data_ptr(), x2d.data_ptr(), K.dt(x2d), w.data_ptr(), K.dt(w), rstd.data_ptr(),
+                                      dx.data_ptr(), dw.data_ptr(), 0, ws.data_ptr(), rows, D, K.stream()), "rmsnorm_bwd")
+    return dx, dw
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def gemm_nt(A, B, out_dtype=None, out=None, kind=EPI_STORE, gate=None, R=None, C2=None, aux=None, aux_gelu=False,
+            partial=None, accumulate=False, k=None):
+    """C[M,N] = epilogue(A[M,K] . B[N,K]^T).  A, B row-major 2-D (row stride free), same dtype.
+    `k` restricts the reduction to the first k columns (used with zero-padded transposed operands)."""
+    K.require_cuda(A, B)
+    A, B = _c2d(A), _c2d(B)
+    if A.dtype != B.dtype:
+        raise K.OtterHipError(f"gemm: operand dtypes differ ({A.dtype} vs {B.dtype})")
+    M, Ka = A.shape
+    N, Kb = B.shape
+    Kd = k if k is not None else Ka
+    if Kd > Ka or Kd > Kb or (k is None and Ka != Kb):
+        raise K.OtterHipError(f"gemm: K mismatch A{tuple(A.shape)} B{tuple(B.shape)} k={k}")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or A.dtype, device=A.device)
+    out = _c2d(out)
+    e = K.EpilogueArgs()
+    e.kind = kind
+    e.accumulate = 1 if accumulate else 0
+    e.gate = K.ptr(gate)
+    if R is not None:
+        R = _c2d(R)
+        e.R, e.ldr, e.r_dtype = R.data_ptr(), R.stride(0), K.dt(R)
+    if C2 is not None:
+        C2 = _c2d(C2)
+        if C2.dtype != out.dtype:
+            raise K.OtterHipError("gemm: C2 must have the dtype of C")
+        e.C2, e.ldc2 = C2.data_ptr(), C2.stride(0)
+    if aux is not None:
+        aux = _c2d(aux)
+        e.aux, e.ldaux, e.aux_dtype = aux.data_ptr(), aux.stride(0), K.dt(aux)
+    e.aux_is_gelu_input = 1 if aux_gelu else 0
+    e.partial = K.ptr(partial)
+    K.check(K.lib().otter_gemm_nt(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0), M, N, Kd,
+                                  K.dt(A), K.dt(out), C.byref(e), K.stream()), "gemm_nt")
+    return out
+
+
+def gemm_num_partials(M, N, dtype) -> int:
+    return int(K.lib().otter_gemm_num_partials(M, N, K.dt_of(dtype)))
+
+
+def reduce_partials(partial, gate=None, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=partial.device)
+    K.check(K.lib().otter_reduce_partials(partial.data_ptr(), partial.numel(), K.ptr(gate), out.data_ptr(), 1 if accumulate else 0,
+                                          K.stream()), "reduce_partials")
+    return out
+
+
+def transpose(src, out_dtype, want_same=False, pad_to=8):
+    """src [rows, cols] -> (src^T as [cols, rows_padded] with zero tail columns, optional same-layout cast copy).
+    rows_padded = roundup(rows, pad_to) so the result can feed gemm_nt as a K-contiguous operand."""
+    K.require_cuda(src)
+    src = _c2d(src)
+    rows, cols = src.shape
+    rp = (rows + pad_to - 1) // pad_to * pad_to
+    if rp != rows:
+        dst_t = torch.zeros((cols, rp), dtype=out_dtype, device=src.device)
+    else:
+        dst_t = torch.empty((cols, rp), dtype=out_dtype, device=src.device)
+    same = torch.empty((rows, cols), dtype=out_dtype, device=src.device) if want_same else None
+    K.check(K.lib().otter_transpose(src.data_ptr(), src.stride(0), K.dt(src), dst_t.data_ptr(), dst_t.stride(0), K.ptr(same),
+                                    cols if want_same else 0, K.dt_of(out_dtype), rows, cols, K.stream()), "transpose")
+    return (dst_t, same) if want_same else dst_t
+
+
+def cast(src, out_dtype):
+    K.require_cuda(src)
+    if src.dtype == out_dtype:
+        return src
+    src = src.contiguous()
+    out = torch.empty(src.shape, dtype=out_dtype, device=src.device)
+    K.check(K.lib().otter_cast(src.data_ptr(), K.dt(src), out.data_ptr(), K.dt(out), src.numel(), K.stream()), "cast")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# attention + mask
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def text_time(media_locations: torch.Tensor, attend_previous: bool = True) -> torch.Tensor:
+    """bool/uint8 [B,T] -> int32 [B,T] (modeling_otter.py:298-311)."""
+    K.require_cuda(media_locations)
+    ml = media_locations.to(torch.uint8).contiguous()
+    B, T = ml.shape
+    tt = torch.empty((B, T), dtype=torch.int32, device=ml.device)
+    K.check(K.lib().otter_text_time(ml.data_ptr(), tt.data_ptr(), B, T, 1 if attend_previous else 0, K.stream()), "text_time")
+    return tt
+
+
+def attn_fwd(q, k, v, H, tt, n_per_media, mask_mode, scale, need_lse=True):
+    """q [B,Tq,H*64]; k, v [B,M,H*64] (may be strided views of one [B,M,2*H*64] buffer).  Returns (o, lse)."""
+    K.require_cuda(q, k, v)
+    B, Tq, HD = q.shape
+    M = k.shape[1]
+    if HD != H * 64:
+        raise K.OtterHipError(f"attention core supports head_dim 64 only (got inner={HD}, heads={H})")
+    if q.stride(2) != 1 or k.stride(2) != 1 or v.stride(2) != 1 or k.stride(1) != v.stride(1):
+        raise K.OtterHipError("attn: bad strides")
+    if q.stride(0) != Tq * q.stride(1) or k.stride(0) != M * k.stride(1) or v.stride(0) != M * v.stride(1):
+        raise K.OtterHipError("attn: batch stride must equal rows*row_stride")
+    o = torch.empty((B, Tq, HD), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device) if need_lse else None
+    K.check(K.lib().otter_attn_fwd(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), o.data_ptr(), o.stride(1),
+                                   K.ptr(lse), K.ptr(tt), B, H, Tq, M, n_per_media, mask_mode, float(scale), K.dt(q), K.stream()),
+            "attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, H, tt, n_per_media, mask_mode, scale, dkv_out=None):
+    """Returns (dq [B,Tq,H*64], dkv [B,M,2*H*64]) -- dk in the first half of the last axis, dv in the second."""
+    B, Tq, HD = q.shape
+    M = k.shape[1]
+    dq = torch.empty((B, Tq, HD), dtype=q.dtype, device=q.device)
+    dkv = dkv_out if dkv_out is not None else torch.empty((B, M, 2 * HD), dtype=q.dtype, device=q.device)
+    dk, dv = dkv[..., :HD], dkv[..., HD:]
+    ws = _ws.get(K.lib().otter_attn_bwd_workspace_bytes(B, H, Tq, M), q.device)
+    do = do.contiguous()
+    K.check(K.lib().otter_attn_bwd(q.data_ptr(), q.stride(1), k.data_ptr(), v.data_ptr(), k.stride(1), o.data_ptr(), do.data_ptr(),
+                                   o.stride(1), lse.data_ptr(), K.ptr(tt), dq.data_ptr(), dq.stride(1), dk.data_ptr(),
+                                   dv.data_ptr(), dkv.stride(1), ws.data_ptr(), B, H, Tq, M, n_per_media, mask_mode, float(scale),
+                                   K.dt(q), K.stream()), "attn_bwd")
+    return dq, dkv
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# misc
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def rope(x, cos, sin, rot_dim=None, inverse=False, out=None):
+    """x [B,S,H,d] contiguous, cos/sin fp32 [S,rot]."""
+    K.require_cuda(x, cos, sin)
+    x = x.contiguous()
+    B, S, H, d = x.shape
+    rot = rot_dim or d
+    y = out if out is not None else torch.empty_like(x)
+    K.check(K.lib().otter_rope(x.data_ptr(), y.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, S, H, d, rot, 1 if inverse else 0,
+                               K.dt(x), K.stream()), "rope")
+    return y
+
+
+def add_frame_embs_(x5, emb):
+    """x5 [b,T,F,v,D] (contiguous, modified in place) += emb[:F] broadcast (modeling_otter.py:224-226)."""
+    b, T, F, v, D = x5.shape
+    assert x5.is_contiguous() and emb.dtype == torch.float32 and emb.is_contiguous()
+    K.check(K.lib().otter_add_frame_embs(x5.data_ptr(), K.dt(x5), emb.data_ptr(), b * T, F, v, D, K.stream()), "add_frame_embs")
+    return x5
+
+
+def add_rows_(dst2d, src2d, src_map: RowMap):
+    """dst2d[r] += src2d[map(r)] (same dtype, same D)."""
+    rows, D = dst2d.shape
+    assert dst2d.is_contiguous() and src2d.is_contiguous() and dst2d.dtype == src2d.dtype
+    K.check(K.lib().otter_add_rows(dst2d.data_ptr(), src2d.data_ptr(), src_map, rows, D, K.dt(dst2d), K.stream()), "add_rows")
+    return dst2d
+
+
+def set_gemm_variant(v: int):
+    K.check(K.lib().otter_gemm_set_variant(int(v)), "gemm_set_variant")
+
+
+def prof_arm_gemm(M, N, Kd, max_events=4096):
+    K.check(K.lib().otter_prof_arm_gemm(M, N, Kd, max_events), "prof_arm")
+
+
+def prof_collect():
+    n = C.c_int(0)
+    ms = C.c_double(0.0)
+    K.check(K.lib().otter_prof_collect(C.byref(n), C.byref(ms)), "prof_collect")
+    return n.value, ms.value
+
+
+def prof_disarm():
+    K.check(K.lib().otter_prof_disarm(), "prof_disarm")

