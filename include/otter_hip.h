@@ -123,6 +123,9 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
 /* selects the bf16 kernel schedule: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 register-staged,
  * 3 = 256x256 direct-to-LDS (global_load_lds).  Process-wide; for A/B measurements. */
 int otter_gemm_set_variant(int variant);
+/* diagnostics for roofline ablations (results are WRONG when non-zero): bit0 = no global loads inside the K loop,
+ * bit1 = no MFMAs.  Never set by the product path. */
+int otter_gemm_set_debug(int flags);
 
 /* out[0] (op) = scale(gate) * sum(partial[0..n))   with scale = (1 - tanh(*gate)^2) when gate != NULL.
  * accumulate != 0 adds into out[0].  Deterministic (single block, fixed order). */

@@ -36,6 +36,7 @@ struct GemmArgs {
     const void* aux; int64_t ldaux; int auxdt; int aux_gelu;
     float* partial;
     int gm, gn;
+    int dbg;  // diagnostics only (otter_gemm_set_debug): bit0 = skip K-loop global loads, bit1 = skip MFMAs
 };
 
 __device__ __forceinline__ void load4(const void* p, int64_t idx, int dt, float (&v)[4]) {
@@ -60,10 +61,11 @@ __device__ __forceinline__ void store4(void* p, int64_t idx, int dt, const float
 }
 
 // epilogue on 4 consecutive output columns of row m; returns this thread's contribution to the gate partial
+template <int EPI>
 __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m, int64_t n, float (&v)[4]) {
     float part = 0.f;
     float o[4];
-    switch (g.kind) {
+    switch (EPI) {
         case OTTER_EPI_STORE: {
             if (g.accumulate) {
                 float c[4];
@@ -112,42 +114,46 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
     return part;
 }
 
-// Epilogue of one 32x32 accumulator block that the owning wave has parked in LDS as [32 rows m][EPI_LD] fp32.
-// Read-back is row-major: lane l handles row (l>>3) + 8*it, columns 4*(l&7)..+3, so 8 lanes cover one 128-B (f32)
-// / 64-B (bf16) run of an output row.  Kept out of line: the accumulator registers are indexed statically by the
-// caller's fully unrolled (mi, ni) loop while everything here may use run-time indices -- inlining 8 copies of the
-// erf-heavy switch made the unroller give up and demoted the accumulators to scratch.
-constexpr int EPI_LD = 36;  // floats per parked row (32 + 4 pad: 16-B aligned rows, 4-row bank skew)
+// Epilogue: a wave parks one 32-row stripe of its sub-tile (two 32x32 accumulator blocks side by side = 32 rows x 64
+// columns) in wave-private LDS as fp32, then reads it back row-major: lane l handles row (l>>4) + 4*it, columns
+// 4*(l&15)..+3, so 16 lanes cover one full 128-B (bf16) / 256-B (f32) run of an output row and every global access of
+// the fused tail (C, C2, residual, aux) is a whole cache line.  The epilogue kind is a template parameter (one copy of
+// the tail per kernel) and the row loop is a run-time loop, so the (mi) loop that indexes the accumulator registers
+// statically stays small enough to be fully unrolled -- a single runtime-switched body made the unroller give up and
+// demoted the accumulators to scratch; an out-of-line body took its arguments through flat (generic) pointers.
+constexpr int EPI_LD = 68;  // floats per parked row (64 + 4 pad; rows stay 16-B aligned)
 
-__device__ __noinline__ float epilogue_block(const GemmArgs& g, float s, const float* __restrict__ blk, int64_t m_base,
-                                             int64_t n_base, int lane) {
+template <int EPI>
+__device__ __forceinline__ float epilogue_stripe(const GemmArgs& g, float s, const float* __restrict__ blk, int64_t m_base,
+                                                 int64_t n_base, int lane) {
     float part = 0.f;
 #pragma unroll 1
-    for (int it = 0; it < 4; ++it) {
-        const int r = (lane >> 3) + 8 * it;
-        const int c = (lane & 7) * 4;
+    for (int it = 0; it < 8; ++it) {
+        const int r = (lane >> 4) + 4 * it;
+        const int c = (lane & 15) * 4;
         const int64_t m = m_base + r, n = n_base + c;
         if (m < g.M && n < g.N) {
             const float4 t = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
             float v[4] = {t.x, t.y, t.z, t.w};
-            part += epilogue4(g, s, m, n, v);
+            part += epilogue4<EPI>(g, s, m, n, v);
         }
     }
     return part;
 }
 
-// park one accumulator block: lane holds row m = lane&31, columns 8*grp + 4*(lane>>5) + 0..3
-__device__ __forceinline__ void park_block(float* __restrict__ blk, const f32x16_t& a, int lane) {
-    float* row = blk + (lane & 31) * EPI_LD + 4 * (lane >> 5);
+// park one accumulator block at column offset col0 of the stripe: lane holds row m = lane&31, columns
+// col0 + 8*grp + 4*(lane>>5) + 0..3
+__device__ __forceinline__ void park_block(float* __restrict__ blk, const f32x16_t& a, int lane, int col0) {
+    float* row = blk + (lane & 31) * EPI_LD + col0 + 4 * (lane >> 5);
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp)
         *reinterpret_cast<float4*>(row + 8 * grp) = make_float4(a[4 * grp + 0], a[4 * grp + 1], a[4 * grp + 2], a[4 * grp + 3]);
 }
 
 // deterministic block reduction of the per-thread partial into partial[blockIdx.x]
-template <int NWAVES>
+template <int NWAVES, int EPI>
 __device__ __forceinline__ void block_partial(const GemmArgs& g, float part, float* red /* LDS, >= NWAVES floats */) {
-    if (g.kind != OTTER_EPI_GATE_BWD || g.partial == nullptr) return;
+    if (EPI != OTTER_EPI_GATE_BWD || g.partial == nullptr) return;
     part = wave_sum(part);
     __syncthreads();  // everyone is done with the LDS that `red` aliases
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -167,15 +173,24 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tile_m, in
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tile_m = swz % g.gm;
-    tile_n = swz / g.gm;
+    if ((g.gm & 7) == 0 && (g.gn & 3) == 0) {
+        // super-tiles of 8 (M) x 4 (N) tiles: the ~32 blocks an XCD has resident at any time form a compact patch, so its
+        // L2 holds 8 A-slabs + 4 B-slabs per K-step (384 KB) instead of 16 + 2 (576 KB) for the plain M-sweep
+        const int st = swz >> 5, w = swz & 31, gms = g.gm >> 3;
+        tile_m = (st % gms) * 8 + (w & 7);
+        tile_n = (st / gms) * 4 + (w >> 3);
+    } else {
+        tile_m = swz % g.gm;
+        tile_n = swz / g.gm;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool GLDS>
+template <int BM, int BN, int WM, int WN, bool GLDS, int EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
+    static_assert(BN / WN == 64, "the epilogue stripe is 64 columns wide");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MI = TM / 32, NI = TN / 32;
@@ -276,8 +291,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
-            if (t + 1 < nk) stage(cur ^ 1, t + 1);
-            compute(cur);
+            if (t + 1 < nk && !(g.dbg & 1)) stage(cur ^ 1, t + 1);
+            if (!(g.dbg & 2)) compute(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -304,8 +319,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
-            if (t + 1 < nk) gload(t + 1);   // in flight under the MFMAs below
-            compute(cur);
+            if (t + 1 < nk && !(g.dbg & 1)) gload(t + 1);   // in flight under the MFMAs below
+            if (!(g.dbg & 2)) compute(cur);
             if (t + 1 < nk) lstore(cur ^ 1);
             __syncthreads();
         }
@@ -319,22 +334,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            park_block(blk, acc[mi][ni], lane);
-            __syncthreads();
-            part += epilogue_block(g, s, blk, m0 + wm * TM + mi * 32, n0 + wn * TN + ni * 32, lane);
-            __syncthreads();
-        }
+        for (int ni = 0; ni < NI; ++ni) park_block(blk, acc[mi][ni], lane, ni * 32);
+        __syncthreads();
+        part += epilogue_stripe<EPI>(g, s, blk, m0 + wm * TM + mi * 32, n0 + wn * TN, lane);
+        __syncthreads();
     }
-    block_partial<WM * WN>(g, part, reinterpret_cast<float*>(smem));
+    block_partial<WM * WN, EPI>(g, part, reinterpret_cast<float*>(smem));
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // exact-f32 MFMA kernel (parity mode): 64x64x32 tile, 4 waves (2x2), one 32x32 accumulator block per wave
 // ------------------------------------------------------------------------------------------------------------
+template <int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = 64, BN = 64, BK = 32, LD = BK + 1;
-    __shared__ __attribute__((aligned(16))) float sm[4 * 32 * EPI_LD > (BM + BN) * LD ? 4 * 32 * EPI_LD : (BM + BN) * LD];
+    __shared__ __attribute__((aligned(16))) float sm[2 * 32 * EPI_LD > (BM + BN) * LD ? 2 * 32 * EPI_LD : (BM + BN) * LD];
     float* As = sm;
     float* Bs = sm + BM * LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -376,11 +390,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
     const float s = g.gate ? tanhf(*g.gate) : 1.0f;
-    float* blk = sm + wave * (32 * EPI_LD);
-    park_block(blk, acc, lane);
+    // the two waves of a row pair (wn = 0, 1) share one 64-column stripe
+    float* blk = sm + wm * (32 * EPI_LD);
+    park_block(blk, acc, lane, wn * 32);
     __syncthreads();
-    float part = epilogue_block(g, s, blk, m0 + wm * 32, n0 + wn * 32, lane);
-    block_partial<4>(g, part, sm);
+    float part = 0.f;
+    {
+        // 32 rows x 64 columns handled by the pair's 128 lanes: lane id within the pair = wn*64 + lane
+        const int pl = wn * 64 + lane;
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int r = (pl >> 4) + 8 * it;
+            const int c = (pl & 15) * 4;
+            const int64_t m = m0 + wm * 32 + r, n = n0 + c;
+            if (m < g.M && n < g.N) {
+                const float4 t = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
+                float v[4] = {t.x, t.y, t.z, t.w};
+                part += epilogue4<EPI>(g, s, m, n, v);
+            }
+        }
+    }
+    block_partial<4, EPI>(g, part, sm);
 }
 
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_t n, const float* __restrict__ gate,
@@ -403,12 +433,13 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
+int g_debug = 0;
 enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_F32 = 10 };
 
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
     if (ab_dtype == OTTER_F32) return CFG_F32;
     int v = g_variant;
-    if (v == 0) v = (cdiv64(M, 256) * cdiv64(N, 256) >= 192) ? CFG_256 : CFG_128;
+    if (v == 0) v = (cdiv64(M, 256) * cdiv64(N, 256) >= 192) ? CFG_256_GLDS : CFG_128;  // GLDS falls back to register staging when K % 64 != 0
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
 }
@@ -434,6 +465,39 @@ int set_smem(KernelT kernel, int bytes) {
     return OTTER_OK;
 }
 
+template <int BM, int BN, int WM, int WN, bool GLDS, int EPI>
+int launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
+    static bool once = false;
+    const int smem = 2 * (BM + BN) * 128;
+    if (!once) {
+        int rc = set_smem(gemm_bf16_kernel<BM, BN, WM, WN, GLDS, EPI>, smem);
+        if (rc) return rc;
+        once = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, GLDS, EPI>), grid, dim3(WM * WN * 64), smem, st, g);
+    return OTTER_OK;
+}
+
+template <int EPI>
+int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
+    if (cfg == CFG_F32) {
+        hipLaunchKernelGGL(gemm_f32_kernel<EPI>, grid, dim3(256), 0, st, g);
+        return OTTER_OK;
+    }
+    if (cfg == CFG_128) return launch_one<128, 128, 2, 2, false, EPI>(grid, st, g);
+    if (cfg == CFG_256) return launch_one<256, 256, 2, 4, false, EPI>(grid, st, g);
+    return launch_one<256, 256, 2, 4, true, EPI>(grid, st, g);
+}
+
+int launch_cfg(int cfg, int kind, dim3 grid, hipStream_t st, const GemmArgs& g) {
+    switch (kind) {
+        case OTTER_EPI_STORE: return launch_epi<OTTER_EPI_STORE>(cfg, grid, st, g);
+        case OTTER_EPI_GELU: return launch_epi<OTTER_EPI_GELU>(cfg, grid, st, g);
+        case OTTER_EPI_SCALE_RES: return launch_epi<OTTER_EPI_SCALE_RES>(cfg, grid, st, g);
+        default: return launch_epi<OTTER_EPI_GATE_BWD>(cfg, grid, st, g);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -454,6 +518,11 @@ int otter_device_check(void) {
 int otter_gemm_set_variant(int variant) {
     if (variant < 0 || variant > 3) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
+    return OTTER_OK;
+}
+
+int otter_gemm_set_debug(int flags) {
+    g_debug = flags;
     return OTTER_OK;
 }
 
@@ -500,30 +569,15 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
     const int cfg = pick_cfg(M, N, K, ab_dtype);
     int bm, bn;
     cfg_tiles(cfg, bm, bn);
+    g.dbg = g_debug;
     g.gm = (int)cdiv64(M, bm);
     g.gn = (int)cdiv64(N, bn);
     const dim3 grid((unsigned)(g.gm * g.gn));
     hipStream_t st = (hipStream_t)stream;
     const bool prof = g_prof.armed && g_prof.M == M && g_prof.N == N && g_prof.K == K && g_prof.n < g_prof.max_events;
     if (prof) hipEventRecord(g_prof.start[g_prof.n], st);
-    if (cfg == CFG_F32) {
-        hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, st, g);
-    } else if (cfg == CFG_128) {
-        static bool once = false;
-        const int smem = 2 * (128 + 128) * 128;
-        if (!once) { int rc = set_smem(gemm_bf16_kernel<128, 128, 2, 2, false>, smem); if (rc) return rc; once = true; }
-        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, 2, false>), grid, dim3(256), smem, st, g);
-    } else if (cfg == CFG_256) {
-        static bool once = false;
-        const int smem = 2 * (256 + 256) * 128;
-        if (!once) { int rc = set_smem(gemm_bf16_kernel<256, 256, 2, 4, false>, smem); if (rc) return rc; once = true; }
-        hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, false>), grid, dim3(512), smem, st, g);
-    } else {
-        static bool once = false;
-        const int smem = 2 * (256 + 256) * 128;
-        if (!once) { int rc = set_smem(gemm_bf16_kernel<256, 256, 2, 4, true>, smem); if (rc) return rc; once = true; }
-        hipLaunchKernelGGL((gemm_bf16_kernel<256, 256, 2, 4, true>), grid, dim3(512), smem, st, g);
-    }
+    int rc = launch_cfg(cfg, g.kind, grid, st, g);
+    if (rc) return rc;
     if (prof) hipEventRecord(g_prof.stop[g_prof.n++], st);
     OTTER_CHECK_LAUNCH("gemm");
     return OTTER_OK;
