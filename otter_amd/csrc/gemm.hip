@@ -49,14 +49,19 @@ __device__ __forceinline__ void load4(const void* p, int64_t idx, int dt, float 
         v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
     }
 }
+// Outputs are written once and not re-read by this kernel: non-temporal stores keep them from displacing the operand
+// panels in the XCD's L2 (and from being written back in the middle of the next tile's K loop).
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 __device__ __forceinline__ void store4(void* p, int64_t idx, int dt, const float (&v)[4]) {
     if (dt == OTTER_BF16) {
-        uint2 r;
+        u32x2_t r;
         r.x = pack2bf(v[0], v[1]);
         r.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>((bf16_t*)p + idx) = r;
+        __builtin_nontemporal_store(r, reinterpret_cast<u32x2_t*>((bf16_t*)p + idx));
     } else {
-        *reinterpret_cast<float4*>((float*)p + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        f32x4_t r = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4_t*>((float*)p + idx));
     }
 }
 
@@ -135,7 +140,11 @@ __device__ __forceinline__ float epilogue_stripe(const GemmArgs& g, float s, con
         if (m < g.M && n < g.N) {
             const float4 t = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
             float v[4] = {t.x, t.y, t.z, t.w};
-            part += epilogue4<EPI>(g, s, m, n, v);
+            if (g.dbg & 16) {  // diagnostics: everything but the global traffic of the tail
+                part += v[0] + v[1] + v[2] + v[3];
+            } else {
+                part += epilogue4<EPI>(g, s, m, n, v);
+            }
         }
     }
     return part;
@@ -152,7 +161,7 @@ __device__ __forceinline__ void park_block(float* __restrict__ blk, const f32x16
 
 // deterministic block reduction of the per-thread partial into partial[blockIdx.x]
 template <int NWAVES, int EPI>
-__device__ __forceinline__ void block_partial(const GemmArgs& g, float part, float* red /* LDS, >= NWAVES floats */) {
+__device__ __forceinline__ void block_partial(const GemmArgs& g, float part, float* red /* LDS, >= NWAVES floats */, int slot) {
     if (EPI != OTTER_EPI_GATE_BWD || g.partial == nullptr) return;
     part = wave_sum(part);
     __syncthreads();  // everyone is done with the LDS that `red` aliases
@@ -162,14 +171,13 @@ __device__ __forceinline__ void block_partial(const GemmArgs& g, float part, flo
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVES; ++w) t += red[w];
-        g.partial[blockIdx.x] = t;
+        g.partial[slot] = t;
     }
 }
 
-__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int& tile_m, int& tile_n) {
+__device__ __forceinline__ void tile_of_block(const GemmArgs& g, int bid, int& tile_m, int& tile_n) {
     // bijective XCD-chunked order (blocks are dispatched round-robin over the 8 XCDs: block b -> XCD b % 8)
     const int nwg = g.gm * g.gn;
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -201,13 +209,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int tile_m, tile_n;
-    tile_of_block(g, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const bf16_t* __restrict__ A = (const bf16_t*)g.A;
     const bf16_t* __restrict__ B = (const bf16_t*)g.B;
     const int64_t K = g.K;
     const int nk = (int)((K + 63) >> 6);
+    const float s = g.gate ? tanhf(*g.gate) : 1.0f;
+    // Persistent over output tiles: a block keeps its CU and walks virtual block ids vb = blockIdx.x + i*gridDim.x
+    // (gridDim.x is a multiple of 8, so vb stays on this block's XCD chunk).  The epilogue stores of tile i drain while
+    // the K loop of tile i+1 is already running -- with one block per tile a CU sat idle until its 128 KB of C had been
+    // acknowledged (the ablation showed the stores costing 4x their stand-alone time).
+    const int ntiles = g.gm * g.gn;
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    int tile_m, tile_n;
+    tile_of_block(g, vb, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
 
     // per-thread chunk coordinates (constant over the K loop)
     const bf16_t* pa[A_CH];
@@ -289,7 +304,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
         stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int t = 0; t < nk; ++t) {
+        const int nk_run = (g.dbg & 8) ? 0 : nk;
+        for (int t = 0; t < nk_run; ++t) {
             const int cur = t & 1;
             if (t + 1 < nk && !(g.dbg & 1)) stage(cur ^ 1, t + 1);
             if (!(g.dbg & 2)) compute(cur);
@@ -328,18 +344,219 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 
     // ---- epilogue: accumulators -> wave-private LDS block -> row-major read-back + fused tail ----
     // (the last K-loop barrier has already retired every read of the operand tiles this aliases)
-    const float s = g.gate ? tanhf(*g.gate) : 1.0f;
     float part = 0.f;
     float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+    if (!(g.dbg & 4)) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) park_block(blk, acc[mi][ni], lane, ni * 32);
-        __syncthreads();
+        // the stripe is wave-private and a wave's LDS instructions execute in program order: no workgroup barrier needed,
+        // the 8 waves run their epilogues independently (wave_barrier only pins the compiler's instruction order)
+        __builtin_amdgcn_wave_barrier();
         part += epilogue_stripe<EPI>(g, s, blk, m0 + wm * TM + mi * 32, n0 + wn * TN, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+    }  // !(dbg & 4)
+    if ((g.dbg & 16) && part == 12345.678f) reinterpret_cast<float*>(g.C)[0] = part;
+    block_partial<WM * WN, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+    __syncthreads();  // every wave is done with the LDS it parked in before the next tile's staging overwrites it
+    }  // persistent tile loop
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 multi-stage kernel (variant 4): 256x256 tile, 4 waves = ONE wave per SIMD, each wave owns 128x128 (4x4 blocks of
+// 32x32 -> 256 accumulator registers, the other half of the 512-entry unified file holds operands), K advanced in
+// steps of 32 through an NS-deep LDS ring filled by global_load_lds_dwordx4.
+//   * larger wave tile: 8 ds_read_b128 per 16 MFMAs (vs 12 in the 8-wave kernel) -> 1/3 less LDS read traffic, which
+//     competes with the LDS-DMA writes for the same LDS port;
+//   * ring depth NS (4 or 5): the DMA of step s+NS-1 is issued at the start of step s, so a load has NS-2 whole steps
+//     to land instead of one K-tile -- the exposed tail of the 2-buffer schedule (latency + burst time of 256 CUs
+//     fetching 64 KB each at once) is what the ablation showed to be un-overlapped;
+//   * "lagged" visibility: the wait that retires step s+2's DMA sits before barrier B(s+1), so after any barrier the
+//     current AND the next step's stages are readable: the first fragments of step s+1 are fetched during the last MFMAs
+//     of step s and the MFMA stream continues straight through the barrier;
+//   * counted s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the DMA queue: guide section 5).
+// LDS image per stage: [256 A rows ; 256 B rows] x 64 B; 16-B slot index XOR (row>>2)&3 (four rows share a 256-B bank
+// row): a ds_read_b128 lane group (16 rows, one logical slot) covers 16 distinct 16-B positions -> conflict-free.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int MS_EPI_LD = 132;  // 128 + 4 floats
+
+template <int EPI>
+__device__ __forceinline__ float epilogue_stripe128(const GemmArgs& g, float s, const float* __restrict__ blk, int64_t m_base,
+                                                    int64_t n_base, int lane) {
+    float part = 0.f;
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+        const int r = (lane >> 5) + 2 * it;
+        const int c = (lane & 31) * 4;
+        const int64_t m = m_base + r, n = n_base + c;
+        if (m < g.M && n < g.N) {
+            const float4 t = *reinterpret_cast<const float4*>(blk + r * MS_EPI_LD + c);
+            float v[4] = {t.x, t.y, t.z, t.w};
+            part += epilogue4<EPI>(g, s, m, n, v);
+        }
+    }
+    return part;
+}
+
+template <int NS, int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_ms_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 32, NT = 256;
+    constexpr int STAGE = (BM + BN) * BK * 2;  // 32 KB
+    constexpr int CH = BM * 4 / NT;            // 16-B chunks per thread per operand per stage = 4
+    constexpr int PD = NS - 1;                 // prefetch distance in steps
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    tile_of_block(g, (int)blockIdx.x, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
+    const int nk = (int)(g.K >> 5);
+
+    const bf16_t* pa[CH];
+    const bf16_t* pb[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const int c = i * NT + tid, row = c >> 2, phys = c & 3;
+        const int slot = phys ^ ((row >> 2) & 3);
+        int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
+        int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
+        pa[i] = A + ga * g.lda + slot * 8;
+        pb[i] = B + gb * g.ldb + slot * 8;
+    }
+    auto issue_a = [&](int step) {
+        const int buf = step % NS;
+        const int64_t koff = (int64_t)step * BK;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int wbase = buf * STAGE + (i * NT + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+        }
+    };
+    auto issue_b = [&](int step) {
+        const int buf = step % NS;
+        const int64_t koff = (int64_t)step * BK;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int wbase = buf * STAGE + BM * 64 + (i * NT + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int step) {
+        issue_a(step);
+        issue_b(step);
+    };
+    // per-lane fragment offsets inside a stage (row part; the k-slot part is added per k-step)
+    int offA[4], offB[4], swzA[4], swzB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 128 + i * 32 + (lane & 31);
+        const int rb = wn * 128 + i * 32 + (lane & 31);
+        offA[i] = ra * 64; swzA[i] = (ra >> 2) & 3;
+        offB[i] = BM * 64 + rb * 64; swzB[i] = (rb >> 2) & 3;
+    }
+    auto load_frags = [&](int step, int ks, bf16x8_t (&fm)[4], bf16x8_t (&fn)[4]) {
+        const char* base = smem + (step % NS) * STAGE;
+        const int slot = 2 * ks + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fm[i] = *reinterpret_cast<const bf16x8_t*>(base + offA[i] + ((slot ^ swzA[i]) << 4));
+            fn[i] = *reinterpret_cast<const bf16x8_t*>(base + offB[i] + ((slot ^ swzB[i]) << 4));
+        }
+    };
+
+    f32x16_t acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    // one quarter of a k-step: the 4 MFMAs of accumulator row mi (operands swapped: a = B rows, b = A rows)
+    auto mma_q = [&](const bf16x8_t (&fm)[4], const bf16x8_t (&fn)[4], int mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[ni], fm[mi], acc[mi][ni], 0, 0, 0);
+    };
+    auto mma = [&](const bf16x8_t (&fm)[4], const bf16x8_t (&fn)[4]) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) mma_q(fm, fn, mi);
+    };
+
+    // ---- prologue: fill PD stages, make stages 0 and 1 visible ----
+#pragma unroll
+    for (int p = 0; p < PD; ++p)
+        if (p < nk) issue(p);
+    // stages 0,1 landed  <=>  at most the groups of stages 2..PD-1 outstanding
+    if (nk >= PD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 2) * 2 * CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    bf16x8_t fm0[4], fn0[4], fm1[4], fn1[4];
+    load_frags(0, 0, fm0, fn0);
+    int s = 0;
+    // steady state: branch-free body so that the compiler can count lgkmcnt (the 8 newest ds_reads stay in flight under
+    // the MFMAs that consume the 8 older ones) -- fragments of the next k-step / next stage are always one MFMA group ahead
+    // One wave per SIMD: nothing else can cover a stall, so inside a step every non-MFMA instruction is issued in the
+    // shadow of MFMAs that are already queued and every wait finds its data long landed:
+    //   Xq0 | ds_read Y | Xq1 | DMA A(s+PD) | Xq2 | DMA B(s+PD) | Xq3 | Yq0 | ds_read X' | Yq1 Yq2 Yq3 | vmcnt | barrier
+    // (X = fragments of k-step 0, fetched during the previous step; Y = k-step 1; X' = k-step 0 of the next stage).
+#define SB() __builtin_amdgcn_sched_barrier(0)
+    for (; s + PD < nk; ++s) {
+        mma_q(fm0, fn0, 0); SB();
+        load_frags(s, 1, fm1, fn1); SB();
+        mma_q(fm0, fn0, 1); SB();
+        issue_a(s + PD); SB();            // ring slot (s+PD)%NS == (s-1)%NS: every wave is past B(s), i.e. done with step s-1
+        mma_q(fm0, fn0, 2); SB();
+        issue_b(s + PD); SB();
+        mma_q(fm0, fn0, 3); SB();
+        mma_q(fm1, fn1, 0); SB();
+        load_frags(s + 1, 0, fm0, fn0); SB();   // stage s+1 is already visible (lagged wait below); in flight across the barrier
+        mma_q(fm1, fn1, 1);
+        mma_q(fm1, fn1, 2);
+        mma_q(fm1, fn1, 3); SB();
+        // retire the DMA of stage s+2 (must be visible after the next barrier); newer groups stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 2) * 2 * CH));
+        __builtin_amdgcn_s_barrier();
+    }
+#undef SB
+    for (; s < nk; ++s) {                 // drain: nothing left to issue
+        load_frags(s, 1, fm1, fn1);
+        mma(fm0, fn0);
+        if (s + 1 < nk) load_frags(s + 1, 0, fm0, fn0);
+        mma(fm1, fn1);
+        asm volatile("s_waitcnt vmcnt(0)");
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue (LDS ring is free: every DMA retired, every wave past the last barrier) ----
+    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
+    float part = 0.f;
+    float* blk = reinterpret_cast<float*>(smem) + wave * (32 * MS_EPI_LD);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            float* row = blk + (lane & 31) * MS_EPI_LD + ni * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp)
+                *reinterpret_cast<float4*>(row + 8 * grp) =
+                    make_float4(acc[mi][ni][4 * grp + 0], acc[mi][ni][4 * grp + 1], acc[mi][ni][4 * grp + 2], acc[mi][ni][4 * grp + 3]);
+        }
+        __syncthreads();
+        part += epilogue_stripe128<EPI>(g, sgate, blk, m0 + wm * 128 + mi * 32, n0 + wn * 128, lane);
         __syncthreads();
     }
-    block_partial<WM * WN, EPI>(g, part, reinterpret_cast<float*>(smem));
+    block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -354,7 +571,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int tile_m, tile_n;
-    tile_of_block(g, tile_m, tile_n);
+    tile_of_block(g, (int)blockIdx.x, tile_m, tile_n);
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const float* __restrict__ A = (const float*)g.A;
     const float* __restrict__ B = (const float*)g.B;
@@ -410,7 +627,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
             }
         }
     }
-    block_partial<4, EPI>(g, part, sm);
+    block_partial<4, EPI>(g, part, sm, (int)blockIdx.x);
 }
 
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_t n, const float* __restrict__ gate,
@@ -434,12 +651,13 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
 int g_debug = 0;
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_F32 = 10 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_F32 = 10 };
 
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
     if (ab_dtype == OTTER_F32) return CFG_F32;
     int v = g_variant;
     if (v == 0) v = (cdiv64(M, 256) * cdiv64(N, 256) >= 192) ? CFG_256_GLDS : CFG_128;  // GLDS falls back to register staging when K % 64 != 0
+    if ((v == CFG_MS4 || v == CFG_MS5) && (K % 32 != 0)) v = CFG_256_GLDS;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
 }
@@ -474,7 +692,11 @@ int launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
         if (rc) return rc;
         once = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, GLDS, EPI>), grid, dim3(WM * WN * 64), smem, st, g);
+    // persistent grid: one resident wave of blocks (256 CUs x blocks that fit per CU), rounded to a multiple of 8
+    const unsigned per_cu = (BM == 256) ? 1u : 2u;
+    unsigned pg = 256u * per_cu;
+    if (grid.x < pg) pg = grid.x;
+    hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, GLDS, EPI>), dim3(pg), dim3(WM * WN * 64), smem, st, g);
     return OTTER_OK;
 }
 
@@ -486,6 +708,19 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     if (cfg == CFG_128) return launch_one<128, 128, 2, 2, false, EPI>(grid, st, g);
     if (cfg == CFG_256) return launch_one<256, 256, 2, 4, false, EPI>(grid, st, g);
+    if (cfg == CFG_MS4 || cfg == CFG_MS5) {
+        const int smem = (cfg == CFG_MS4 ? 4 : 5) * 32768;
+        if (cfg == CFG_MS4) {
+            static bool once = false;
+            if (!once) { int rc = set_smem(gemm_bf16_ms_kernel<4, EPI>, smem); if (rc) return rc; once = true; }
+            hipLaunchKernelGGL((gemm_bf16_ms_kernel<4, EPI>), grid, dim3(256), smem, st, g);
+        } else {
+            static bool once = false;
+            if (!once) { int rc = set_smem(gemm_bf16_ms_kernel<5, EPI>, smem); if (rc) return rc; once = true; }
+            hipLaunchKernelGGL((gemm_bf16_ms_kernel<5, EPI>), grid, dim3(256), smem, st, g);
+        }
+        return OTTER_OK;
+    }
     return launch_one<256, 256, 2, 4, true, EPI>(grid, st, g);
 }
 
@@ -516,7 +751,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 3) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 5) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }

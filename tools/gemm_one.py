@@ -1,0 +1,16 @@
+"""Run the FFN-shape bf16 GEMM a few times (for rocprofv3 --pmc passes).  Usage: gemm_one.py [variant] [iters] [M N K]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from otter_amd import ops
+v = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+it = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+M, N, K = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (4096, 16384, 4096)
+A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
+C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+ops.set_gemm_variant(v)
+for _ in range(it):
+    ops.gemm_nt(A, B, out=C)
+torch.cuda.synchronize()
+print("done", v, it, M, N, K)
