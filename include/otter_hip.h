@@ -64,6 +64,13 @@ int otter_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const voi
                         int y_dtype, otter_rowmap y_map, void* y2, float* mean, float* rstd, int64_t rows, int64_t D,
                         float eps, void* stream);
 
+/* Fused residual add + LayerNorm: xsum = x + delta (stored with x's dtype), y = LN(xsum).  Replaces the
+ * `x = x + resid_attn_dropout(b); m = norm_2(x)` pair of MPTBlock.forward (mpt/blocks.py:83-84): one pass over the
+ * residual stream instead of two.  Backward = otter_layernorm_bwd with dres = d(xsum). */
+int otter_add_layernorm_fwd(const void* x, int x_dtype, const void* delta, int delta_dtype, void* xsum, const void* gamma,
+                            const void* beta, int w_dtype, void* y, int y_dtype, float* mean, float* rstd, int64_t rows,
+                            int64_t D, float eps, void* stream);
+
 /* dx = LN'(dy) (+ dres if given, same dtype as dx).  dy is read through dy_map (same convention as the forward's
  * y_map).  dgamma/dbeta (fp32, [D]) are OVERWRITTEN (or accumulated when accumulate != 0).  ws: see
  * otter_layernorm_bwd_workspace_bytes.  gamma may be NULL (treated as ones); dbeta may be NULL. */

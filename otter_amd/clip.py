@@ -26,8 +26,12 @@ class _Embeddings(nn.Module):
     def forward(self, pixel_values):
         N = pixel_values.shape[0]
         w = self.patch_embedding.weight
-        pe = F.conv2d(pixel_values.to(w.dtype), w, stride=self.patch_embedding.stride)
-        pe = pe.flatten(2).transpose(1, 2)
+        # stride == kernel: the patch "convolution" is a plain GEMM over unfolded patches (MIOpen picked a naive conv kernel
+        # for this shape: 1.2 ms per call in the round-1 profile)
+        P = w.shape[-1]
+        C, Hh, Ww = pixel_values.shape[1:]
+        pat = pixel_values.to(w.dtype).reshape(N, C, Hh // P, P, Ww // P, P).permute(0, 2, 4, 1, 3, 5).reshape(N, -1, C * P * P)
+        pe = F.linear(pat, w.reshape(w.shape[0], -1))
         cls = self.class_embedding.to(pe.dtype).expand(N, 1, -1)
         return torch.cat([cls, pe], dim=1) + self.position_embedding.weight.to(pe.dtype)
 

@@ -24,7 +24,8 @@ template <int NCH, bool RMS>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const void* __restrict__ x, int xdt, const void* __restrict__ gamma,
                                                        const void* __restrict__ beta, int wdt, void* __restrict__ y, int ydt,
                                                        otter_rowmap ymap, void* __restrict__ y2, float* __restrict__ mean,
-                                                       float* __restrict__ rstd, int64_t rows, int D, float eps) {
+                                                       float* __restrict__ rstd, int64_t rows, int D, float eps,
+                                                       const void* __restrict__ delta, int ddt, void* __restrict__ xsum) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -35,6 +36,13 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const void* __restrict__ 
         const int col = c * 512 + lane * 8;
         if (col < D) {
             load8(x, row * D + col, xdt, v[c]);
+            if (delta) {  // fused residual add: xsum = x + delta (stored in x's dtype), normalise xsum
+                float dl[8];
+                load8(delta, row * D + col, ddt, dl);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[c][i] = round_to(v[c][i] + dl[i], xdt);
+                store8(xsum, row * D + col, xdt, v[c]);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += RMS ? v[c][i] * v[c][i] : v[c][i];
         } else {
@@ -235,12 +243,13 @@ int pick_rch(int64_t rows) {
 
 template <bool RMS>
 int launch_fwd(const void* x, int xdt, const void* gamma, const void* beta, int wdt, void* y, int ydt, otter_rowmap ymap,
-               void* y2, float* mean, float* rstd, int64_t rows, int64_t D, float eps, hipStream_t st) {
+               void* y2, float* mean, float* rstd, int64_t rows, int64_t D, float eps, hipStream_t st,
+               const void* delta = nullptr, int ddt = 0, void* xsum = nullptr) {
     OTTER_REQUIRE(x && y && rows > 0 && D > 0, "norm_fwd: null pointer or empty shape");
     OTTER_REQUIRE(D % 8 == 0 && D <= 8192, "norm_fwd: D=%ld must be a multiple of 8 and <= 8192", (long)D);
     const int nch = pick_nch(D);
     dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
-#define L(N) hipLaunchKernelGGL((norm_fwd_kernel<N, RMS>), grid, block, 0, st, x, xdt, gamma, beta, wdt, y, ydt, ymap, y2, mean, rstd, rows, (int)D, eps)
+#define L(N) hipLaunchKernelGGL((norm_fwd_kernel<N, RMS>), grid, block, 0, st, x, xdt, gamma, beta, wdt, y, ydt, ymap, y2, mean, rstd, rows, (int)D, eps, delta, ddt, xsum)
     switch (nch) {
         case 1: L(1); break;
         case 2: L(2); break;
@@ -296,6 +305,15 @@ int otter_layernorm_fwd(const void* x, int x_dtype, const void* gamma, const voi
                         void* stream) {
     return launch_fwd<false>(x, x_dtype, gamma, beta, w_dtype, y, y_dtype, y_map, y2, mean, rstd, rows, D, eps,
                              (hipStream_t)stream);
+}
+
+int otter_add_layernorm_fwd(const void* x, int x_dtype, const void* delta, int delta_dtype, void* xsum, const void* gamma,
+                            const void* beta, int w_dtype, void* y, int y_dtype, float* mean, float* rstd, int64_t rows, int64_t D,
+                            float eps, void* stream) {
+    OTTER_REQUIRE(delta && xsum, "add_layernorm_fwd: delta and xsum are required");
+    otter_rowmap id = {0, 0, 0};
+    return launch_fwd<false>(x, x_dtype, gamma, beta, w_dtype, y, y_dtype, id, nullptr, mean, rstd, rows, D, eps,
+                             (hipStream_t)stream, delta, delta_dtype, xsum);
 }
 
 int64_t otter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (int64_t)pick_rch(rows) * 2 * D * 4; }

@@ -115,6 +115,40 @@ class LayerNormFn(torch.autograd.Function):
                 db.to(weight.dtype) if (db is not None and ctx.has_bias) else None, None, None)
 
 
+class AddLayerNormFn(torch.autograd.Function):
+    """(xsum, y) = (x + delta, LN(x + delta)) in one pass over the residual stream (mpt/blocks.py:83-84)."""
+
+    @staticmethod
+    def forward(ctx, x, delta, weight, bias, eps, out_dtype):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        d2 = delta.reshape(-1, shp[-1]).contiguous()
+        xsum, y, mean, rstd = ops.add_layernorm_fwd(x2, d2, weight.detach() if weight is not None else None,
+                                                    bias.detach() if bias is not None else None, out_dtype, eps)
+        ctx.save_for_backward(xsum, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        ctx.shp = shp
+        ctx.ddtype = delta.dtype
+        return xsum.view(shp), y.view(shp)
+
+    @staticmethod
+    def backward(ctx, d_xsum, dy):
+        xsum, weight, mean, rstd = ctx.saved_tensors
+        need_dw = weight is not None and weight.requires_grad
+        D = ctx.shp[-1]
+        dres = d_xsum.reshape(-1, D).contiguous() if d_xsum is not None else None
+        dx, dg, db = ops.layernorm_bwd(dy.reshape(-1, D).contiguous(), xsum, weight.detach() if weight is not None else None, mean,
+                                       rstd, xsum.dtype, dres=dres, need_dw=need_dw, need_dbeta=ctx.has_bias)
+        ddelta = ops.cast(dx, ctx.ddtype) if ctx.needs_input_grad[1] else None
+        return (dx.view(ctx.shp), ddelta.view(ctx.shp) if ddelta is not None else None,
+                dg.to(weight.dtype) if dg is not None else None, db.to(weight.dtype) if (db is not None and ctx.has_bias) else None,
+                None, None)
+
+
+def add_layer_norm(x, delta, weight, bias, eps=1e-5, out_dtype=None):
+    return AddLayerNormFn.apply(x, delta, weight, bias, eps, out_dtype or x.dtype)
+
+
 def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
     return LayerNormFn.apply(x, weight, bias, eps, out_dtype or x.dtype)
 

@@ -86,6 +86,10 @@ class _Norm(nn.LayerNorm):
     def forward(self, x):
         return OF.layer_norm(x, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
 
+    def add_forward(self, x, delta):
+        """(x + delta, LN(x + delta)) fused in one HIP pass over the residual stream."""
+        return OF.add_layer_norm(x, delta, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
+
 
 class MPTMLP(nn.Module):
     def __init__(self, d_model, expansion_ratio, bias):
@@ -139,8 +143,7 @@ class MPTBlock(nn.Module):
     def forward(self, x, past_key_value=None, attn_bias=None, attention_mask=None, is_causal=True):
         a = self.norm_1(x)
         b, past_key_value = self.attn(a, past_key_value=past_key_value, attn_bias=attn_bias, is_causal=is_causal)
-        x = x + b
-        m = self.norm_2(x)
+        x, m = self.norm_2.add_forward(x, b)   # x = x + b ; m = norm_2(x)
         x = x + self.ffn(m)
         return x, None, past_key_value
 

@@ -63,6 +63,22 @@ def layernorm_fwd(x2d, gamma, beta, out_dtype, eps=1e-5, y=None, ymap: Optional[
     return y, mean, rstd
 
 
+def add_layernorm_fwd(x2d, delta2d, gamma, beta, out_dtype, eps=1e-5, need_stats=True):
+    """(xsum, y, mean, rstd) with xsum = x + delta (x's dtype) and y = LN(xsum)."""
+    K.require_cuda(x2d, delta2d, gamma, beta)
+    assert x2d.is_contiguous() and delta2d.is_contiguous() and x2d.shape == delta2d.shape
+    rows, D = x2d.shape
+    xsum = torch.empty_like(x2d)
+    y = torch.empty((rows, D), dtype=out_dtype, device=x2d.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device) if need_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device) if need_stats else None
+    wdt = K.dt(gamma) if gamma is not None else F32
+    K.check(K.lib().otter_add_layernorm_fwd(x2d.data_ptr(), K.dt(x2d), delta2d.data_ptr(), K.dt(delta2d), xsum.data_ptr(),
+                                            K.ptr(gamma), K.ptr(beta), wdt, y.data_ptr(), K.dt(y), K.ptr(mean), K.ptr(rstd), rows, D,
+                                            float(eps), K.stream()), "add_layernorm_fwd")
+    return xsum, y, mean, rstd
+
+
 def layernorm_bwd(dy, x2d, gamma, mean, rstd, dx_dtype, dres=None, dymap: Optional[RowMap] = None, need_dw=True,
                   need_dbeta=True, need_dx=True):
     """Returns (dx, dgamma, dbeta) -- dgamma/dbeta fp32."""

@@ -107,6 +107,19 @@ def test_layernorm_rowmap_and_nobias(ops):
     assert relmax(host(cs), dyl.sum(0)) < 1e-5
 
 
+def test_add_layernorm_fused(ops):
+    """xsum = x + delta (fp32 residual, bf16 delta), y = LN(xsum) in bf16 -- the MPT block's residual-add + norm_2 pair."""
+    r = rng(123)
+    rows, D = 70, 4096
+    x = r.standard_normal((rows, D)).astype(np.float32)
+    delta = bf16_round(r.standard_normal((rows, D)).astype(np.float32))
+    w = (1 + 0.1 * r.standard_normal(D)).astype(np.float32)
+    xsum, y, mean, rstd = ops.add_layernorm_fwd(to_dev(x), to_dev(delta, torch.bfloat16), to_dev(w), None, torch.bfloat16)
+    assert np.array_equal(host(xsum), x + delta)  # fp32 add of the same operands: bit-exact
+    y_ref, _ = O.layer_norm_fwd(x + delta, w, None)
+    assert relmax(host(y), y_ref) < 1e-2 and y.dtype == torch.bfloat16
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_rmsnorm(ops, dt):
     r = rng(9)
