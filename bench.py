@@ -216,8 +216,15 @@ def main():
         if n_launch > 0:
             avg_s = gemm_ms / n_launch / 1e3
             ach = 2.0 * M * N * Kd / avg_s / 1e12
+            # HBM-side traffic per launch comes from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+            # WRITE_SIZE) committed under profiles/; PMC collection cannot share a run with the timed region.
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_ffn.json")
+            if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
+                with open(pmc) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256> M=%d N=%d K=%d" % (M, N, Kd), "achieved": round(ach, 1),
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
         out = {
             "metric": "image-text pairs/s (train step) OTTER-MPT7B, 1 img+512 tok",

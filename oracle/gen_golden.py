@@ -233,6 +233,44 @@ def case_otter_tiny(mo, name="otter_tiny", seed=7):
             "missing": [str(m) for m in missing.missing_keys]}
 
 
+def tiny_llama_configs():
+    t = synth.TINY
+    text_cfg = dict(architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=64, intermediate_size=128,
+                    num_hidden_layers=4, num_attention_heads=4, num_key_value_heads=4, vocab_size=t["vocab"],
+                    max_position_embeddings=64, rms_norm_eps=1e-6, tie_word_embeddings=False, _name_or_path="tiny-llama")
+    vis_cfg = dict(hidden_size=1024, intermediate_size=t["clip_inter"], num_hidden_layers=t["clip_layers"],
+                   num_attention_heads=t["clip_heads"], image_size=t["image"], patch_size=t["patch"],
+                   hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=64)
+    return text_cfg, vis_cfg
+
+
+def case_otter_tiny_llama(mo, name="otter_tiny_llama", seed=13):
+    """Config-C4 composition at toy size: LLaMA decoder (HF class, as the reference uses) + video input (F=3 frames,
+    max_num_frames=4 -> frame_embs) + gated cross-attention every 2 layers."""
+    from src.otter_ai.models.otter.configuration_otter import OtterConfig  # type: ignore
+
+    mo.AutoTokenizer.from_pretrained = staticmethod(lambda *a, **k: StubTokenizer())
+    text_cfg, vis_cfg = tiny_llama_configs()
+    cfg = OtterConfig(vision_config=vis_cfg, text_config=dict(text_cfg), cross_attn_every_n_layers=2, max_num_frames=4)
+    model = mo.OtterForConditionalGeneration(cfg)
+    model.eval()
+    shapes, missing = load_synth(model, seed, "")
+    vision_x, ids, mask, labels = synth.tiny_batch(seed, F=3)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model.init_weights()
+    out = model(vision_x=torch.from_numpy(vision_x), lang_x=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask),
+                labels=torch.from_numpy(labels))
+    out.loss.backward()
+    res = {"logits": out.logits.detach().numpy(), "loss": np.array(out.loss.item(), dtype=np.float64)}
+    trainable = sorted(n for n, p in model.named_parameters() if p.requires_grad)
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            put_grad(res, n, p.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return {"seed": seed, "state_dict_shapes": {k: list(v) for k, v in shapes.items()}, "trainable": trainable}
+
+
 def case_llama(name="llama_ops", seed=11):
     from transformers.models.llama.modeling_llama import LlamaRMSNorm, apply_rotary_pos_emb
 
@@ -272,6 +310,7 @@ def main():
     meta["xattn_noprev"] = case_xattn(mo, "xattn_noprev", 3, "base", attend_previous=False)
     meta["xattn_ge"] = case_xattn(mo, "xattn_ge", 3, "base", immediate=False)
     meta["otter_tiny"] = case_otter_tiny(mo)
+    meta["otter_tiny_llama"] = case_otter_tiny_llama(mo)
     meta["llama_ops"] = case_llama()
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)

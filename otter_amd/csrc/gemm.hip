@@ -105,8 +105,11 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (g.aux_gelu) {
-                    part += v[i] * gelu_erf(a[i]);
-                    o[i] = s * v[i] * gelu_erf_grad(a[i]);
+                    // gelu and gelu' share the erf: one transcendental chain instead of two
+                    const float cdf = 0.5f * (1.0f + erff(a[i] * 0.70710678118654752440f));
+                    const float pdf = 0.39894228040143267794f * expf(-0.5f * a[i] * a[i]);
+                    part += v[i] * (a[i] * cdf);
+                    o[i] = s * v[i] * (cdf + a[i] * pdf);
                 } else {
                     part += v[i] * a[i];
                     o[i] = s * v[i];

@@ -149,6 +149,32 @@ def add_layer_norm(x, delta, weight, bias, eps=1e-5, out_dtype=None):
     return AddLayerNormFn.apply(x, delta, weight, bias, eps, out_dtype or x.dtype)
 
 
+class RMSNormFn(torch.autograd.Function):
+    """LlamaRMSNorm (xformers_model/llama.py:95-112 / HF): y = w * (x * rsqrt(mean(x^2) + eps)).to(x.dtype), config C4."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        y, rstd = ops.rmsnorm_fwd(x2, weight.detach(), eps)
+        ctx.save_for_backward(x2, weight, rstd)
+        ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, ctx.shp[-1]).contiguous()
+        if dy2.dtype != x2.dtype:
+            dy2 = ops.cast(dy2, x2.dtype)
+        dx, dw = ops.rmsnorm_bwd(dy2, x2, weight.detach(), rstd)
+        return dx.view(ctx.shp), (dw.to(weight.dtype) if weight.requires_grad else None), None
+
+
+def rms_norm(x, weight, eps=1e-6):
+    return RMSNormFn.apply(x, weight, eps)
+
+
 def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
     return LayerNormFn.apply(x, weight, bias, eps, out_dtype or x.dtype)
 

@@ -349,6 +349,20 @@ def _load_tokenizer(name: str, vocab_size: int):
         return OtterStubTokenizer(vocab_size)
 
 
+def _use_hip_rmsnorm(lang_encoder: nn.Module) -> None:
+    """Config C4 (LLaMA host, third-party transformers class as in the reference): route every LlamaRMSNorm through the
+    HIP RMSNorm kernel (same parameters, same state-dict keys; only `forward` is rebound)."""
+    import types
+
+    def _fwd(self, hidden_states):
+        eps = getattr(self, "variance_epsilon", getattr(self, "eps", 1e-6))
+        return OF.rms_norm(hidden_states, self.weight, eps)
+
+    for mod in lang_encoder.modules():
+        if mod.__class__.__name__ == "LlamaRMSNorm":
+            mod.forward = types.MethodType(_fwd, mod)
+
+
 class OtterPreTrainedModel(PreTrainedModel):
     config_class = OtterConfig
     base_model_prefix = "otter"
@@ -375,6 +389,7 @@ class OtterForConditionalGeneration(OtterPreTrainedModel):
 
             text_tokenizer = _load_tokenizer(getattr(tc, "_name_or_path", "") or "llama", tc.vocab_size)
             lang_encoder = LlamaForCausalLM(tc)
+            _use_hip_rmsnorm(lang_encoder)
         else:
             raise NotImplementedError(arch)
         vision_encoder = CLIPVisionModel(config.vision_config)

@@ -139,3 +139,20 @@ def test_grouped_params_rule(model):
     assert wd and all("gated_cross_attn_layer" in n and "gate" not in n.split(".")[-1] and "norm" not in n and "bias" not in n
                       for n in wd)
     assert any(n.endswith("feed_forward.1.weight") for n in wd) and not any("feed_forward.0.weight" in n for n in wd) is False or True
+
+
+def test_llama_host_state_dict_contract():
+    """LLaMA-backed variant (config C4): same keys/shapes/trainable set as the reference built on the same transformers."""
+    from oracle.gen_golden import tiny_llama_configs
+    from otter_amd.configuration_otter import OtterConfig
+    from otter_amd.modeling_otter import OtterForConditionalGeneration
+
+    text_cfg, vis_cfg = tiny_llama_configs()
+    model = OtterForConditionalGeneration(OtterConfig(vision_config=vis_cfg, text_config=dict(text_cfg),
+                                                       cross_attn_every_n_layers=2, max_num_frames=4))
+    ref = G.meta()["otter_tiny_llama"]
+    want = {k: tuple(v) for k, v in ref["state_dict_shapes"].items()}
+    got = {k: tuple(v.shape) for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    assert got == want
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == ref["trainable"]
+    assert model.perceiver.frame_embs.shape == (4, 1024)
