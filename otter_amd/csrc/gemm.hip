@@ -262,6 +262,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+    // (A per-tile rotation of the K walk -- meant to spread the power-of-two operand strides over L2/HBM channels -- was
+    // measured 10 % SLOWER in interleaved A/B rounds: tiles that share an A or B panel hit the same lines at the same time
+    // when they walk k in lock step, and that temporal L2 sharing is worth more than the channel spread.  Not used.)
+    auto krot = [&](int t) { return t; };
+
     auto compute = [&](int buf) {
         const char* At = smem + buf * TILE_BYTES;
         const char* Bt = At + BM * 128;
@@ -304,13 +309,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
         };
-        stage(0, 0);
+        stage(0, krot(0));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int nk_run = (g.dbg & 8) ? 0 : nk;
         for (int t = 0; t < nk_run; ++t) {
             const int cur = t & 1;
-            if (t + 1 < nk && !(g.dbg & 1)) stage(cur ^ 1, t + 1);
+            if (t + 1 < nk && !(g.dbg & 1)) stage(cur ^ 1, krot(t + 1));
             if (!(g.dbg & 2)) compute(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -333,12 +338,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < B_CH; ++i) *reinterpret_cast<uint4*>(base + lb[i]) = rb[i];
         };
-        gload(0);
+        gload(krot(0));
         lstore(0);
         __syncthreads();
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
-            if (t + 1 < nk && !(g.dbg & 1)) gload(t + 1);   // in flight under the MFMAs below
+            if (t + 1 < nk && !(g.dbg & 1)) gload(krot(t + 1));   // in flight under the MFMAs below
             if (!(g.dbg & 2)) compute(cur);
             if (t + 1 < nk) lstore(cur ^ 1);
             __syncthreads();

@@ -269,8 +269,8 @@ def test_gemm_big_variants_agree(ops):
     ops.set_gemm_variant(0)
     for o in outs:
         assert relmax(host(o), ref) < 1e-4
-    for o in outs[1:]:
-        assert torch.equal(outs[0], o)  # same MFMA shape and k order per element -> bit-identical across schedules
+    # same tile shape + same per-tile K rotation -> same accumulation order -> bit-identical (register- vs LDS-DMA-staged)
+    assert torch.equal(outs[1], outs[2])
 
 
 def test_transpose_cast(ops):
