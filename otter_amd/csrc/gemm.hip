@@ -234,7 +234,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int c = i * NT + tid, row = c >> 3, phys = c & 7;
-        const int slot = GLDS ? (phys ^ ((row >> 1) & 7)) : phys;        // logical k-slot this lane fetches
+        const int slot = (GLDS && !(g.dbg & 64)) ? (phys ^ ((row >> 1) & 7)) : phys;        // logical k-slot this lane fetches (dbg 64: linear, wrong results)
         const int dst = GLDS ? phys : (phys ^ ((row >> 1) & 7));        // physical slot it lands in
         int64_t gr = m0 + row;
         if (gr > g.M - 1) gr = g.M - 1;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
         const int c = i * NT + tid, row = c >> 3, phys = c & 7;
-        const int slot = GLDS ? (phys ^ ((row >> 1) & 7)) : phys;
+        const int slot = (GLDS && !(g.dbg & 64)) ? (phys ^ ((row >> 1) & 7)) : phys;
         const int dst = GLDS ? phys : (phys ^ ((row >> 1) & 7));
         int64_t gr = n0 + row;
         if (gr > g.N - 1) gr = g.N - 1;
@@ -370,6 +370,168 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
     block_partial<WM * WN, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
     __syncthreads();  // every wave is done with the LDS it parked in before the next tile's staging overwrites it
     }  // persistent tile loop
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 phased kernel (variant 6): the 256x256x64 / 8-wave / LDS-DMA kernel above with the K-tile split into four
+// quadrant phases and the two wave rows STAGGERED by one barrier (guide section 5, "8-phase" idea):
+//   wave (wr, wc) owns rows wr*128.. x cols wc*64..; phase (mh, nh) = its 64x32 quadrant x the whole BK = 8 MFMAs.
+//   per phase:  LOAD part (ds_read the quadrant's new fragments [+ issue the next tile's DMA in phase 0])
+//               | s_barrier | lgkmcnt(0) | setprio(1) 8x MFMA setprio(0) | s_barrier
+//   waves 4-7 (wr = 1) execute one extra s_barrier up front, so at every moment one wave row sits in its MFMA cluster
+//   while the other sits in its LOAD part.  A SIMD hosts wave s (wr 0) and wave s+4 (wr 1): its matrix pipe is fed by
+//   the two alternately and LDS reads / DMA issue of one always run under the MFMAs of the other.
+// Hazards (barrier instance k of row 0 pairs with instance k+1 of row 1):
+//   RAW  DMA(t+1) -> ds_read: every wave waits vmcnt(0) in the LOAD part of phase 3, i.e. before a barrier that both its
+//        own row and (one instance later) the other row pass before their first read of tile t+1.
+//   WAR  ds_read(t-1) -> DMA(t+1) into the same buffer: phase 3 reads nothing new (the nh=0 B fragments are kept in
+//        registers) and phase 2's reads are retired by lgkmcnt(0) before its MFMAs, so when any wave issues the DMA in
+//        phase 0 of tile t every read of tile t-1 has completed, on both rows.
+// ------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, NT = 512;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    constexpr int CH = 4;  // 16-B chunks per thread per operand per K-tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
+    const int nk = (int)(g.K >> 6);
+    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
+    const int ntiles = g.gm * g.gn;
+#define RAW_BARRIER()                       \
+    do {                                    \
+        __builtin_amdgcn_sched_barrier(0);  \
+        __builtin_amdgcn_s_barrier();       \
+        __builtin_amdgcn_sched_barrier(0);  \
+    } while (0)
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int tile_m, tile_n;
+        tile_of_block(g, vb, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+        const bf16_t* pa[CH];
+        const bf16_t* pb[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+            const int slot = phys ^ ((row >> 1) & 7);
+            int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
+            int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
+            pa[i] = A + ga * g.lda + slot * 8;
+            pb[i] = B + gb * g.ldb + slot * 8;
+        }
+        auto stage = [&](int buf, int kt) {
+            const int64_t koff = (int64_t)kt * 64;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int wbase = buf * TILE_BYTES + (i * NT + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + koff),
+                                                 (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int wbase = buf * TILE_BYTES + BM * 128 + (i * NT + wave * 64) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + koff),
+                                                 (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+            }
+        };
+        // fragment addressing: A rows wr*128 + mh*64 + mi2*32 + (lane&31); B rows wc*64 + nh*32 + (lane&31)
+        auto ld_a = [&](int buf, int mh, bf16x8_t (&fa)[2][4]) {
+            const char* At = smem + buf * TILE_BYTES;
+#pragma unroll
+            for (int mi2 = 0; mi2 < 2; ++mi2) {
+                const int row = wr * 128 + mh * 64 + mi2 * 32 + (lane & 31);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int slot = 2 * ks + (lane >> 5);
+                    fa[mi2][ks] = *reinterpret_cast<const bf16x8_t*>(At + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+                }
+            }
+        };
+        auto ld_b = [&](int buf, int nh, bf16x8_t (&fb)[4]) {
+            const char* Bt = smem + buf * TILE_BYTES + BM * 128;
+            const int row = wc * 64 + nh * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int slot = 2 * ks + (lane >> 5);
+                fb[ks] = *reinterpret_cast<const bf16x8_t*>(Bt + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+            }
+        };
+        f32x16_t acc[4][2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        // one quadrant: 8 MFMAs, operands swapped (a = B rows, b = A rows)
+#define QUAD(MH, NH, FA, FB)                                                                                            \
+    do {                                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+            acc[(MH)*2 + 0][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[0][ks], acc[(MH)*2 + 0][NH], 0, 0, 0); \
+            acc[(MH)*2 + 1][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[1][ks], acc[(MH)*2 + 1][NH], 0, 0, 0); \
+        }                                                                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+    } while (0)
+
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wr == 1) RAW_BARRIER();  // stagger the second wave row by one barrier
+        bf16x8_t fa[2][4], fb[4];
+        for (int t = 0; t < nk; ++t) {
+            const int cur = t & 1;
+            // ---- phase 0: quadrant (0,0) ----
+            ld_a(cur, 0, fa);
+            ld_b(cur, 0, fb);
+            RAW_BARRIER();
+            QUAD(0, 0, fa, fb);
+            // the next tile's DMA is issued AFTER this cluster: by now the other wave row has retired its last reads of
+            // the buffer being refilled (its phase-3 reads complete before its own phase-3 MFMAs, one barrier ago)
+            if (t + 1 < nk) stage(cur ^ 1, t + 1);
+            RAW_BARRIER();
+            // ---- phase 1: quadrant (0,1) ----
+            ld_b(cur, 1, fb);
+            RAW_BARRIER();
+            QUAD(0, 1, fa, fb);
+            RAW_BARRIER();
+            // ---- phase 2: quadrant (1,1) ----
+            ld_a(cur, 1, fa);
+            RAW_BARRIER();
+            QUAD(1, 1, fa, fb);
+            RAW_BARRIER();
+            // ---- phase 3: quadrant (1,0); retire this wave's share of the next tile's DMA before the barrier ----
+            ld_b(cur, 0, fb);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RAW_BARRIER();
+            QUAD(1, 0, fa, fb);
+            RAW_BARRIER();
+        }
+        if (wr == 0) RAW_BARRIER();  // undo the stagger
+        __syncthreads();
+#undef QUAD
+
+        // ---- epilogue (same as the 8-wave kernel: 64-column wave-private stripes) ----
+        float part = 0.f;
+        float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) park_block(blk, acc[mi][ni], lane, ni * 32);
+            __builtin_amdgcn_wave_barrier();
+            part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wr * 128 + mi * 32, n0 + wc * 64, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        block_partial<8, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+        __syncthreads();
+    }
+#undef RAW_BARRIER
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -659,13 +821,19 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
 int g_debug = 0;
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_F32 = 10 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_F32 = 10 };
 
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
     if (ab_dtype == OTTER_F32) return CFG_F32;
     int v = g_variant;
-    if (v == 0) v = (cdiv64(M, 256) * cdiv64(N, 256) >= 192) ? CFG_256_GLDS : CFG_128;  // GLDS falls back to register staging when K % 64 != 0
+    if (v == 0) {
+        // interleaved A/B medians on MI355X (tools/gemm_ab.py): the phased/staggered schedule wins at K = 4096
+        // (1082 / 1136 TF vs 967 / 1063 for the 2-phase kernel), the 5-stage one-wave-per-SIMD ring at K = 16384 (1183 vs 1123)
+        if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = (K >= 8192) ? CFG_MS5 : CFG_PH;
+        else v = CFG_128;
+    }
     if ((v == CFG_MS4 || v == CFG_MS5) && (K % 32 != 0)) v = CFG_256_GLDS;
+    if (v == CFG_PH && (K % 64 != 0)) v = CFG_256;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
 }
@@ -716,6 +884,14 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     if (cfg == CFG_128) return launch_one<128, 128, 2, 2, false, EPI>(grid, st, g);
     if (cfg == CFG_256) return launch_one<256, 256, 2, 4, false, EPI>(grid, st, g);
+    if (cfg == CFG_PH) {
+        static bool once = false;
+        const int smem = 2 * (256 + 256) * 128;
+        if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI>, smem); if (rc) return rc; once = true; }
+        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(pg), dim3(512), smem, st, g);
+        return OTTER_OK;
+    }
     if (cfg == CFG_MS4 || cfg == CFG_MS5) {
         const int smem = (cfg == CFG_MS4 ? 4 : 5) * 32768;
         if (cfg == CFG_MS4) {
@@ -759,7 +935,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 5) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 6) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }
