@@ -172,9 +172,12 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("OTTER_FORCE_DIST") == "1"  # the env switch exercises the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from otter_amd import ops
     from otter_amd.train import TrainStep
@@ -182,13 +185,14 @@ def main():
     if args.gemm_variant:
         ops.set_gemm_variant(args.gemm_variant)
     model = build_model(device, seed=0, debug_layers=args.debug_layers)  # identical replica on every rank (same seed)
-    step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16)
+    step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16,
+                     force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1")
     B, T = args.batch, args.seq
     batch = synth_batch(model, B, T, device, seed=1000 + rank)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -206,7 +210,7 @@ def main():
     n_launch, gemm_ms = ops.prof_collect()
     ops.prof_disarm()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -248,7 +252,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -412,53 +412,56 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
         int tile_m, tile_n;
         tile_of_block(g, vb, tile_m, tile_n);
         const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-        const bf16_t* pa[CH];
-        const bf16_t* pb[CH];
+        // global side: 32-bit per-lane byte offsets from a wave-uniform base (SGPR base + VGPR offset addressing: half the
+        // address registers of 64-bit pointers and no per-tile 64-bit VALU adds; the host guarantees the operands span < 4 GB)
+        uint32_t oa[CH], ob[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int c = i * NT + tid, row = c >> 3, phys = c & 7;
             const int slot = phys ^ ((row >> 1) & 7);
             int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
             int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
-            pa[i] = A + ga * g.lda + slot * 8;
-            pb[i] = B + gb * g.ldb + slot * 8;
+            oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
+            ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
         }
         auto stage = [&](int buf, int kt) {
-            const int64_t koff = (int64_t)kt * 64;
+            const char* abase = reinterpret_cast<const char*>(A) + (size_t)kt * 128;
+            const char* bbase = reinterpret_cast<const char*>(B) + (size_t)kt * 128;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int wbase = buf * TILE_BYTES + (i * NT + wave * 64) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + koff),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + oa[i]),
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int wbase = buf * TILE_BYTES + BM * 128 + (i * NT + wave * 64) * 16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + koff),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bbase + ob[i]),
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
         };
-        // fragment addressing: A rows wr*128 + mh*64 + mi2*32 + (lane&31); B rows wc*64 + nh*32 + (lane&31)
+        // LDS side: the swizzle term (row>>1)&7 only depends on lane&31 (every row offset used below is a multiple of 32),
+        // so ONE base per k-step and operand (8 VGPRs) + compile-time immediates reach every fragment of the wave.
+        const int swz = ((lane & 31) >> 1) & 7;
+        int la[4], lb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = (2 * ks + (lane >> 5)) ^ swz;
+            la[ks] = (wr * 128 + (lane & 31)) * 128 + (slot << 4);
+            lb[ks] = BM * 128 + (wc * 64 + (lane & 31)) * 128 + (slot << 4);
+        }
         auto ld_a = [&](int buf, int mh, bf16x8_t (&fa)[2][4]) {
-            const char* At = smem + buf * TILE_BYTES;
+            const char* base = smem + buf * TILE_BYTES + mh * (64 * 128);
 #pragma unroll
-            for (int mi2 = 0; mi2 < 2; ++mi2) {
-                const int row = wr * 128 + mh * 64 + mi2 * 32 + (lane & 31);
+            for (int mi2 = 0; mi2 < 2; ++mi2)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int slot = 2 * ks + (lane >> 5);
-                    fa[mi2][ks] = *reinterpret_cast<const bf16x8_t*>(At + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-                }
-            }
+                for (int ks = 0; ks < 4; ++ks)
+                    fa[mi2][ks] = *reinterpret_cast<const bf16x8_t*>(base + la[ks] + mi2 * (32 * 128));
         };
         auto ld_b = [&](int buf, int nh, bf16x8_t (&fb)[4]) {
-            const char* Bt = smem + buf * TILE_BYTES + BM * 128;
-            const int row = wc * 64 + nh * 32 + (lane & 31);
+            const char* base = smem + buf * TILE_BYTES + nh * (32 * 128);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int slot = 2 * ks + (lane >> 5);
-                fb[ks] = *reinterpret_cast<const bf16x8_t*>(Bt + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-            }
+            for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const bf16x8_t*>(base + lb[ks]);
         };
         f32x16_t acc[4][2];
 #pragma unroll
@@ -833,7 +836,7 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
         else v = CFG_128;
     }
     if ((v == CFG_MS4 || v == CFG_MS5) && (K % 32 != 0)) v = CFG_256_GLDS;
-    if (v == CFG_PH && (K % 64 != 0)) v = CFG_256;
+    if (v == CFG_PH && (K % 64 != 0 || M * K >= (int64_t(1) << 31) || N * K >= (int64_t(1) << 31))) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
 }

@@ -40,8 +40,9 @@ class GradReducer:
     """Bucketed, overlapped gradient averaging across the data-parallel group."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 640 << 20,
-                 process_group: Optional[dist.ProcessGroup] = None, grad_dtype: torch.dtype = torch.float32):
+                 process_group: Optional[dist.ProcessGroup] = None, grad_dtype: torch.dtype = torch.float32, force: bool = False):
         self.group = process_group
+        self.force = force  # run the collectives even with one rank (exercises the RCCL path on a single GPU)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         ps = [p for p in params if p.requires_grad]
         if not ps:
@@ -89,7 +90,7 @@ class GradReducer:
             v.add_(p.grad)
             p.grad = v
         b.pending -= 1
-        if b.pending == 0 and self.sync and self.world > 1:
+        if b.pending == 0 and self.sync and (self.world > 1 or self.force):
             self._launch(b)
 
     def _launch(self, b: _Bucket):
@@ -103,7 +104,7 @@ class GradReducer:
     def wait(self):
         """Block the current stream until every bucket is reduced.  Buckets whose hooks never fired (unused parameters)
         are reduced here so that all ranks issue the same collectives."""
-        if self.world > 1 and self.sync:
+        if (self.world > 1 or self.force) and self.sync:
             for b in self.buckets:
                 if b.work is None:
                     self._launch(b)

@@ -57,7 +57,7 @@ class TrainStep:
 
     def __init__(self, model, lr: float = 1e-5, weight_decay: float = 0.1, max_grad_norm: float = 1.0,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, process_group=None, bucket_bytes: int = 640 << 20,
-                 fused_optimizer: bool = True):
+                 fused_optimizer: bool = True, force_reducer: bool = False):
         self.model = model
         self.max_grad_norm = max_grad_norm
         self.autocast_dtype = autocast_dtype
@@ -68,7 +68,7 @@ class TrainStep:
         self.optimizer = torch.optim.AdamW(groups, lr=lr, fused=bool(fused_optimizer and dev.type == "cuda"))
         self.world = torch.distributed.get_world_size(process_group) if torch.distributed.is_initialized() else 1
         # single rank: gradients stay ordinary .grad tensors (no bucket indirection, nothing to reduce)
-        self.reducer = GradReducer(self.params, bucket_bytes, process_group) if self.world > 1 else None
+        self.reducer = GradReducer(self.params, bucket_bytes, process_group, force=force_reducer) if (self.world > 1 or force_reducer) else None
 
     def zero_grad(self):
         if self.reducer is not None:
