@@ -99,6 +99,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Phi(u) = 0.5 (1 + erf(u / sqrt 2)) and phi(u) = exp(-u^2/2) / sqrt(2 pi) from ONE exponential:
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class), 1 rcp + 5 fma + 1 v_exp_f32 instead of
+// libm's branchy erff (~40 VALU) plus a separate expf.  Used by the GEMM epilogues (GELU forward, gate/GELU backward).
+__device__ __forceinline__ void gelu_cdf_pdf(float u, float& cdf, float& pdf) {
+    const float x = fabsf(u) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    const float e = __expf(-x * x);  // = exp(-u^2 / 2)
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_abs = p * t * e;             // 1 - erf(|x|)
+    const float half = 0.5f * erfc_abs;
+    cdf = u >= 0.f ? 1.0f - half : half;
+    pdf = 0.39894228040143267794f * e;
+}
+
 // exact-erf GELU and its derivative (nn.GELU() default, approximate='none')
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float u) {

@@ -37,6 +37,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ sr
     }
 }
 
+// Vectorised variant (rows, cols and leading dimensions multiples of 8, 16-B aligned bases): every global access is a
+// 16-B (bf16) / 32-B (f32) vector, the transposition itself happens in LDS (odd pitch -> the strided column reads spread
+// over 8 banks).  The scalar kernel above remains the general fallback.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void transpose_vec_kernel(const S* __restrict__ src, int64_t ld_src, D* __restrict__ dst_t,
+                                                            int64_t ld_dst_t, D* __restrict__ dst_same, int64_t ld_dst_same,
+                                                            int64_t rows, int64_t cols) {
+    constexpr int P = 65;
+    __shared__ D tile[64 * P];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = threadIdx.x + 256 * j, row = q >> 3, cc = (q & 7) * 8;
+        if (r0 + row < rows && c0 + cc < cols) {
+            float v[8];
+            Vec8<S>::load(src + (r0 + row) * ld_src + c0 + cc, v);
+            if (dst_same) Vec8<D>::store(dst_same + (r0 + row) * ld_dst_same + c0 + cc, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tile[row * P + cc + i] = cvt<float, D>(v[i]);
+        }
+    }
+    __syncthreads();
+    if (dst_t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = threadIdx.x + 256 * j, col = q >> 3, rc = (q & 7) * 8;
+            if (c0 + col < cols && r0 + rc < rows) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = cvt<D, float>(tile[(rc + i) * P + col]);
+                Vec8<D>::store(dst_t + (c0 + col) * ld_dst_t + r0 + rc, v);
+            }
+        }
+    }
+}
+
 template <typename S, typename D>
 __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -138,7 +174,13 @@ int otter_transpose(const void* src, int64_t ld_src, int src_dtype, void* dst_t,
     dim3 grid((unsigned)cdiv64(cols, 64), (unsigned)cdiv64(rows, 64)), block(256);
     OTTER_REQUIRE(grid.y <= 65535, "transpose: too many row tiles");
     hipStream_t st = (hipStream_t)stream;
-#define L(S, D) hipLaunchKernelGGL((transpose_kernel<S, D>), grid, block, 0, st, (const S*)src, ld_src, (D*)dst_t, ld_dst_t, (D*)dst_same, ld_dst_same, rows, cols)
+    const bool vec = rows % 8 == 0 && cols % 8 == 0 && ld_src % 8 == 0 && (!dst_t || ld_dst_t % 8 == 0) &&
+                     (!dst_same || ld_dst_same % 8 == 0) && (((uintptr_t)src | (uintptr_t)dst_t | (uintptr_t)dst_same) & 15) == 0;
+#define L(S, D)                                                                                                              \
+    do {                                                                                                                     \
+        if (vec) hipLaunchKernelGGL((transpose_vec_kernel<S, D>), grid, block, 0, st, (const S*)src, ld_src, (D*)dst_t, ld_dst_t, (D*)dst_same, ld_dst_same, rows, cols); \
+        else hipLaunchKernelGGL((transpose_kernel<S, D>), grid, block, 0, st, (const S*)src, ld_src, (D*)dst_t, ld_dst_t, (D*)dst_same, ld_dst_same, rows, cols); \
+    } while (0)
     if (src_dtype == OTTER_F32 && dst_dtype == OTTER_F32) L(float, float);
     else if (src_dtype == OTTER_F32 && dst_dtype == OTTER_BF16) L(float, bf16_t);
     else if (src_dtype == OTTER_BF16 && dst_dtype == OTTER_F32) L(bf16_t, float);

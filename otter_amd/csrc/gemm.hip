@@ -87,7 +87,11 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
         case OTTER_EPI_GELU: {
             if (g.C2) store4(g.C2, m * g.ldc2 + n, g.cdt, v);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = gelu_erf(v[i]);
+            for (int i = 0; i < 4; ++i) {
+                float cdf, pdf;
+                gelu_cdf_pdf(v[i], cdf, pdf);
+                o[i] = v[i] * cdf;
+            }
             store4(g.C, m * g.ldc + n, g.cdt, o);
             break;
         }
@@ -106,8 +110,8 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
             for (int i = 0; i < 4; ++i) {
                 if (g.aux_gelu) {
                     // gelu and gelu' share the erf: one transcendental chain instead of two
-                    const float cdf = 0.5f * (1.0f + erff(a[i] * 0.70710678118654752440f));
-                    const float pdf = 0.39894228040143267794f * expf(-0.5f * a[i] * a[i]);
+                    float cdf, pdf;
+                    gelu_cdf_pdf(a[i], cdf, pdf);
                     part += v[i] * (a[i] * cdf);
                     o[i] = s * v[i] * (cdf + a[i] * pdf);
                 } else {

@@ -282,6 +282,14 @@ def test_transpose_cast(ops):
     assert np.array_equal(host(ops.cast(to_dev(a), torch.bfloat16)), bf16_round(a))
     t32 = ops.transpose(to_dev(a[:64]), torch.float32)
     assert np.array_equal(host(t32), a[:64].T)
+    # vectorised path (everything a multiple of 8), ragged tile edges, both dtype directions
+    b = r.standard_normal((200, 136)).astype(np.float32)
+    tb, sb = ops.transpose(to_dev(b), torch.bfloat16, want_same=True)
+    assert np.array_equal(host(tb), bf16_round(b).T) and np.array_equal(host(sb), bf16_round(b))
+    tbb = ops.transpose(to_dev(b, torch.bfloat16), torch.bfloat16)
+    assert np.array_equal(host(tbb), bf16_round(b).T)
+    tbf = ops.transpose(to_dev(b, torch.bfloat16), torch.float32)
+    assert np.array_equal(host(tbf), bf16_round(b).T)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
