@@ -85,6 +85,14 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and os.environ.get("OTTER_NO_AUTOBUILD") != "1":
+        # build-on-demand (hipcc, gfx950) -- still no alternative compute path: if this fails we raise below
+        try:
+            from . import build as _build
+
+            _build.build(verbose=False)
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise OtterHipError(
             f"{LIB_PATH} is missing: build it with `python -m otter_amd.build` (hipcc --offload-arch=gfx950). "

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 //        registers) and phase 2's reads are retired by lgkmcnt(0) before its MFMAs, so when any wave issues the DMA in
 //        phase 0 of tile t every read of tile t-1 has completed, on both rows.
 // ------------------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool CNT>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, NT = 512;
     constexpr int TILE_BYTES = (BM + BN) * 128;
@@ -444,6 +444,44 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
         };
+        // CNT schedule: the K-tile is fed as four half-tiles of 128 rows -- A_h(mh) = rows {wr*128 + mh*64 + 0..63 : wr},
+        // B_h(nh) = rows {wc*64 + nh*32 + 0..31 : wc} -- i.e. exactly the rows ONE quadrant phase reads.  Two DMA pieces per
+        // thread per half-tile; they are issued one or two per phase and retired with COUNTED vmcnt (never drained in
+        // steady state): A_h0,B_h0(t+1) in phase 0, B_h1(t+1) in phase 1, A_h1(t+1) in phase 2 -> every half-tile has three
+        // phases to land and the wait in phase q-1 for the rows phase q reads leaves the 2-3 newest half-tiles in flight.
+        uint32_t oah[2][2], obh[2][2];
+        if constexpr (CNT) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = i * NT + tid, rl = c >> 3, phys = c & 7;
+                    const int ra = (rl >> 6) * 128 + h * 64 + (rl & 63);
+                    const int rb = (rl >> 5) * 64 + h * 32 + (rl & 31);
+                    int64_t ga = m0 + ra; if (ga > g.M - 1) ga = g.M - 1;
+                    int64_t gb = n0 + rb; if (gb > g.N - 1) gb = g.N - 1;
+                    oah[h][i] = (uint32_t)((ga * g.lda + (phys ^ ((ra >> 1) & 7)) * 8) * 2);
+                    obh[h][i] = (uint32_t)((gb * g.ldb + (phys ^ ((rb >> 1) & 7)) * 8) * 2);
+                }
+        }
+        auto stage_ah = [&](int buf, int kt, int h) {
+            const char* abase = reinterpret_cast<const char*>(A) + (size_t)kt * 128;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int wbase = buf * TILE_BYTES + (i * 128 + h * 64 + wave * 8) * 128;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + oah[h][i]),
+                                                 (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+            }
+        };
+        auto stage_bh = [&](int buf, int kt, int h) {
+            const char* bbase = reinterpret_cast<const char*>(B) + (size_t)kt * 128;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int wbase = buf * TILE_BYTES + BM * 128 + ((2 * i + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8) * 128;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bbase + obh[h][i]),
+                                                 (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
+            }
+        };
         // LDS side: the swizzle term (row>>1)&7 only depends on lane&31 (every row offset used below is a multiple of 32),
         // so ONE base per k-step and operand (8 VGPRs) + compile-time immediates reach every fragment of the wave.
         const int swz = ((lane & 31) >> 1) & 7;
@@ -487,11 +525,49 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);                                                                                  \
     } while (0)
 
-        stage(0, 0);
+        if constexpr (CNT) {
+            stage_ah(0, 0, 0); stage_bh(0, 0, 0); stage_bh(0, 0, 1); stage_ah(0, 0, 1);
+        } else {
+            stage(0, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (wr == 1) RAW_BARRIER();  // stagger the second wave row by one barrier
         bf16x8_t fa[2][4], fb[4];
+        if constexpr (CNT) {
+            for (int t = 0; t < nk; ++t) {
+                const int cur = t & 1;
+                const bool more = t + 1 < nk;
+                // ---- phase 0: quadrant (0,0) ----
+                if (more) { stage_ah(cur ^ 1, t + 1, 0); stage_bh(cur ^ 1, t + 1, 0); }
+                ld_a(cur, 0, fa);
+                ld_b(cur, 0, fb);
+                // rows read in phase 1 (B_h1 of this tile) must have landed before the barrier after the next cluster
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 0, fa, fb);
+                RAW_BARRIER();
+                // ---- phase 1: quadrant (0,1) ----
+                if (more) stage_bh(cur ^ 1, t + 1, 1);
+                ld_b(cur, 1, fb);
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // A_h1 of this tile (phase 2)
+                RAW_BARRIER();
+                QUAD(0, 1, fa, fb);
+                RAW_BARRIER();
+                // ---- phase 2: quadrant (1,1) ----
+                if (more) stage_ah(cur ^ 1, t + 1, 1);
+                ld_a(cur, 1, fa);
+                RAW_BARRIER();
+                QUAD(1, 1, fa, fb);
+                RAW_BARRIER();
+                // ---- phase 3: quadrant (1,0) ----
+                ld_b(cur, 0, fb);
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A_h0, B_h0 of the next tile (its phase 0)
+                RAW_BARRIER();
+                QUAD(1, 0, fa, fb);
+                RAW_BARRIER();
+            }
+        } else
         for (int t = 0; t < nk; ++t) {
             const int cur = t & 1;
             // ---- phase 0: quadrant (0,0) ----
@@ -828,7 +904,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
 int g_debug = 0;
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_F32 = 10 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_F32 = 10 };
 
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
     if (ab_dtype == OTTER_F32) return CFG_F32;
@@ -840,7 +916,7 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
         else v = CFG_128;
     }
     if ((v == CFG_MS4 || v == CFG_MS5) && (K % 32 != 0)) v = CFG_256_GLDS;
-    if (v == CFG_PH && (K % 64 != 0 || M * K >= (int64_t(1) << 31) || N * K >= (int64_t(1) << 31))) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
+    if ((v == CFG_PH || v == CFG_PHC) && (K % 64 != 0 || M * K >= (int64_t(1) << 31) || N * K >= (int64_t(1) << 31))) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
 }
@@ -891,12 +967,18 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     if (cfg == CFG_128) return launch_one<128, 128, 2, 2, false, EPI>(grid, st, g);
     if (cfg == CFG_256) return launch_one<256, 256, 2, 4, false, EPI>(grid, st, g);
-    if (cfg == CFG_PH) {
-        static bool once = false;
+    if (cfg == CFG_PH || cfg == CFG_PHC) {
         const int smem = 2 * (256 + 256) * 128;
-        if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI>, smem); if (rc) return rc; once = true; }
         unsigned pg = grid.x < 256u ? grid.x : 256u;
-        hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI>), dim3(pg), dim3(512), smem, st, g);
+        if (cfg == CFG_PH) {
+            static bool once = false;
+            if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI, false>, smem); if (rc) return rc; once = true; }
+            hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, false>), dim3(pg), dim3(512), smem, st, g);
+        } else {
+            static bool once = false;
+            if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI, true>, smem); if (rc) return rc; once = true; }
+            hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, true>), dim3(pg), dim3(512), smem, st, g);
+        }
         return OTTER_OK;
     }
     if (cfg == CFG_MS4 || cfg == CFG_MS5) {
@@ -942,7 +1024,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 6) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 7) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }

@@ -1,4 +1,4 @@
-"""Load-path experiment on the FFN-shape GEMM (v3): loads-only time with and without the source-side swizzle."""
+"""Load-path experiment on the FFN-shape GEMM: loads-only time of register staging (v2) vs LDS-DMA (v3)."""
 import json, os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,12 +16,14 @@ M, N, K = 4096, 16384, 4096
 A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
 C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-ops.set_gemm_variant(3)
-cfgs = {"full": 0, "full_linear": 64, "loadsonly": 2 | 16, "loadsonly_linear": 2 | 16 | 64, "computeonly": 1 | 16, "neither": 3 | 16}
+cfgs = {"v3_full": (3, 16), "v3_loads": (3, 2 | 16), "v3_compute": (3, 1 | 16), "v3_neither": (3, 3 | 16),
+        "v2_full": (2, 16), "v2_loads": (2, 2 | 16), "v2_compute": (2, 1 | 16), "v2_neither": (2, 3 | 16)}
 res = {k: [] for k in cfgs}
 for r in range(4):
-    for k, f in cfgs.items():
+    for k, (v, f) in cfgs.items():
+        ops.set_gemm_variant(v)
         _capi.lib().otter_gemm_set_debug(f)
         res[k].append(bench(lambda: ops.gemm_nt(A, B, out=C)))
 _capi.lib().otter_gemm_set_debug(0)
+ops.set_gemm_variant(0)
 print(json.dumps({k: [round(min(v), 1), round(statistics.median(v), 1)] for k, v in res.items()}))
