@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libotter_hip.so")
+LIB_PATH = os.environ.get("OTTER_LIB_PATH") or os.path.join(_HERE, "lib", "libotter_hip.so")  # override: diagnostics builds only
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_SCALE_RES, EPI_GATE_BWD = 0, 1, 2, 3

@@ -30,6 +30,20 @@ def _newer(target: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+def build_diag(mask: int, verbose: bool = True) -> str:
+    """Ablation build of the GEMM (-DOTTER_DIAG=mask, see csrc/gemm.hip) -> lib/libotter_hip_diag<mask>.so.  Only
+    tools/gemm_ablate.py loads these (through OTTER_LIB_PATH); their results are wrong by construction."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    build(verbose=verbose)  # the other objects
+    cc = hipcc()
+    obj = os.path.join(LIBDIR, "gemm_diag%d.o" % mask)
+    out = os.path.join(LIBDIR, "libotter_hip_diag%d.so" % mask)
+    subprocess.check_call([cc, *FLAGS, "-DOTTER_DIAG=%d" % mask, "-c", os.path.join(CSRC, "gemm.hip"), "-o", obj])
+    others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "gemm.hip"]
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "otter_hip.h")]
@@ -59,4 +73,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--diag" in sys.argv:
+        print(build_diag(int(sys.argv[sys.argv.index("--diag") + 1])))
+    else:
+        print(build(force="--force" in sys.argv))

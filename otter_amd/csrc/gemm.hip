@@ -377,6 +377,125 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// bf16 wave-specialised kernel (variant 8): 8 MFMA waves + 4 LOADER waves (768 threads, 3 waves per SIMD).
+// Why: ablations with a diagnostics build (tools/gemm_load_exp.py) showed that in every schedule above the LDS-DMA stream
+// and the MFMA stream do not overlap -- MFMAs on register-resident fragments (no LDS reads) + DMA take the SUM of the two
+// (447 us vs 273 + 278 - 56), at an unthrottled 2.38 GHz.  A wave issues in order: once the CU's vector-memory queue is
+// full, a wave that still has global_load_lds instructions to issue sits on them until the queue drains (64 KB per K-tile
+// = ~0.86 us per CU, the same as the MFMA time of the tile), and cannot issue its MFMAs meanwhile.  So the DMA is issued
+// by waves that have nothing else to do: waves 8-11 (one per SIMD) each fetch 16 of the 64 1-KB pieces of the [A ; B]
+// K-tile into the buffer the MFMA waves will read next, wait for their own vmcnt and meet the others at the per-tile
+// barrier; waves 0-7 never touch vector memory inside the K loop (fragment reads + MFMAs only, 2 per SIMD).  One loader
+// is not enough: measured 3.9 us per K-tile with a single loader wave (~17 GB/s of LDS-DMA per wave).
+// Register budget: 12 waves -> 3 per SIMD -> <= 168 VGPRs per wave for the whole kernel.
+// ------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(768) void gemm_bf16_ws_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, WN = 4;
+    constexpr int TM = 128, TN = 64, MI = 4, NI = 2;
+    constexpr int TILE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 8;   // waves 8..11: one loader per SIMD (a single wave sustains only ~17-25 GB/s of LDS-DMA)
+    const int lw = wave & 3;
+    const int wm = (wave & 7) / WN, wn = (wave & 7) % WN;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
+    const int nk = (int)(g.K >> 6);
+    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
+    const int ntiles = g.gm * g.gn;
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int tile_m, tile_n;
+        tile_of_block(g, vb, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+
+        // ---- loader: piece j (0..63) = rows 8j..8j+7 of the stacked [A rows ; B rows] tile, 1 KB, lane -> (row, slot) ----
+        const int lrow = lane >> 3, phys = lane & 7;
+        auto fetch_tile = [&](int buf, int kt) {
+            const int64_t koff = (int64_t)kt * 64;
+#pragma unroll 4
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = lw * 16 + jj;                        // loader lw fetches pieces 16*lw .. 16*lw+15
+                const int row = (j & 31) * 8 + lrow;               // row inside the operand tile
+                const int slot = phys ^ ((row >> 1) & 7);
+                const bf16_t* src;
+                if (j < 32) {
+                    int64_t gr = m0 + row; if (gr > g.M - 1) gr = g.M - 1;
+                    src = A + gr * g.lda + koff + slot * 8;
+                } else {
+                    int64_t gr = n0 + row; if (gr > g.N - 1) gr = g.N - 1;
+                    src = B + gr * g.ldb + koff + slot * 8;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * TILE_BYTES + j * 1024), 16, 0, 0);
+            }
+        };
+
+        if (loader) {
+            // ---- loader wave: no accumulators live anywhere on this path; same barrier sequence as the MFMA waves ----
+            fetch_tile(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int t = 0; t < nk; ++t) {
+                if (t + 1 < nk) fetch_tile((t & 1) ^ 1, t + 1);   // that buffer was released by the barrier that ended step t-1
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+            block_partial<8, EPI>(g, 0.f, reinterpret_cast<float*>(smem), vb);
+            __syncthreads();
+        } else {
+            f32x16_t acc[MI][NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            __syncthreads();
+            for (int t = 0; t < nk; ++t) {
+                const char* At = smem + (t & 1) * TILE_BYTES;
+                const char* Bt = At + BM * 128;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int slot = 2 * ks + (lane >> 5);
+                    bf16x8_t fa[NI], fb[MI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int row = wn * TN + ni * 32 + (lane & 31);
+                        fa[ni] = *reinterpret_cast<const bf16x8_t*>(Bt + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int row = wm * TM + mi * 32 + (lane & 31);
+                        fb[mi] = *reinterpret_cast<const bf16x8_t*>(At + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ni], fb[mi], acc[mi][ni], 0, 0, 0);
+                }
+                __syncthreads();
+            }
+            // ---- epilogue: wave-private LDS stripes ----
+            float part = 0.f;
+            float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) park_block(blk, acc[mi][ni], lane, ni * 32);
+                __builtin_amdgcn_wave_barrier();
+                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * TM + mi * 32, n0 + wn * TN, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+            block_partial<8, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // bf16 phased kernel (variant 6): the 256x256x64 / 8-wave / LDS-DMA kernel above with the K-tile split into four
 // quadrant phases and the two wave rows STAGGERED by one barrier (guide section 5, "8-phase" idea):
 //   wave (wr, wc) owns rows wr*128.. x cols wc*64..; phase (mh, nh) = its 64x32 quadrant x the whole BK = 8 MFMAs.
@@ -392,8 +511,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
 //        registers) and phase 2's reads are retired by lgkmcnt(0) before its MFMAs, so when any wave issues the DMA in
 //        phase 0 of tile t every read of tile t-1 has completed, on both rows.
 // ------------------------------------------------------------------------------------------------------------
-template <int EPI, bool CNT>
+// Compile-time diagnostics for the ablation builds of tools/gemm_ablate.py (`python -m otter_amd.build --diag N` writes
+// lib/libotter_hip_diagN.so; results are WRONG by construction): 1 = no DMA, 2 = no MFMA, 4 = no epilogue, 8 = no ds_read.
+// Compile-time on purpose: a runtime flag inside these lambdas costs the product kernels 3-4x (section 4.1 of DESIGN.md).
+#ifndef OTTER_DIAG
+#define OTTER_DIAG 0
+#endif
+template <int EPI, int SCH, bool BUF>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
+    constexpr bool CNT = SCH >= 1;
     constexpr int BM = 256, BN = 256, NT = 512;
     constexpr int TILE_BYTES = (BM + BN) * 128;
     constexpr int CH = 4;  // 16-B chunks per thread per operand per K-tile
@@ -405,6 +531,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
     const bf16_t* __restrict__ B = (const bf16_t*)g.B;
     const int nk = (int)(g.K >> 6);
     const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
+    // BUF: buffer addressing for the DMA (SGPR resource descriptor + 32-bit per-lane offset + scalar K offset): no
+    // per-piece 64-bit VALU address arithmetic, and the hardware range check clamps reads past the end of the operand
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    if constexpr (BUF) {
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
+    }
     const int ntiles = g.gm * g.gn;
 #define RAW_BARRIER()                       \
     do {                                    \
@@ -429,17 +562,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
             ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
         }
         auto stage = [&](int buf, int kt) {
+            if constexpr ((OTTER_DIAG & 1) != 0) return;
             const char* abase = reinterpret_cast<const char*>(A) + (size_t)kt * 128;
             const char* bbase = reinterpret_cast<const char*>(B) + (size_t)kt * 128;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int wbase = buf * TILE_BYTES + (i * NT + wave * 64) * 16;
+                if constexpr (BUF)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
+                                                             (int)oa[i], kt * 128, 0, 0);
+                else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + oa[i]),
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int wbase = buf * TILE_BYTES + BM * 128 + (i * NT + wave * 64) * 16;
+                if constexpr (BUF)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
+                                                             (int)ob[i], kt * 128, 0, 0);
+                else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bbase + ob[i]),
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
@@ -464,20 +606,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
                     obh[h][i] = (uint32_t)((gb * g.ldb + (phys ^ ((rb >> 1) & 7)) * 8) * 2);
                 }
         }
-        auto stage_ah = [&](int buf, int kt, int h) {
+        auto stage_ah = [&](int buf, int kt, int h, int i0 = 0, int i1 = 2) {
+            if constexpr ((OTTER_DIAG & 1) != 0) return;
             const char* abase = reinterpret_cast<const char*>(A) + (size_t)kt * 128;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = i0; i < i1; ++i) {
                 const int wbase = buf * TILE_BYTES + (i * 128 + h * 64 + wave * 8) * 128;
+                if constexpr (BUF)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
+                                                             (int)oah[h][i], kt * 128, 0, 0);
+                else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + oah[h][i]),
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
         };
-        auto stage_bh = [&](int buf, int kt, int h) {
+        auto stage_bh = [&](int buf, int kt, int h, int i0 = 0, int i1 = 2) {
+            if constexpr ((OTTER_DIAG & 1) != 0) return;
             const char* bbase = reinterpret_cast<const char*>(B) + (size_t)kt * 128;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = i0; i < i1; ++i) {
                 const int wbase = buf * TILE_BYTES + BM * 128 + ((2 * i + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8) * 128;
+                if constexpr (BUF)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
+                                                             (int)obh[h][i], kt * 128, 0, 0);
+                else
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bbase + obh[h][i]),
                                                  (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
             }
@@ -493,6 +645,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
             lb[ks] = BM * 128 + (wc * 64 + (lane & 31)) * 128 + (slot << 4);
         }
         auto ld_a = [&](int buf, int mh, bf16x8_t (&fa)[2][4]) {
+            if constexpr ((OTTER_DIAG & 8) != 0) return;
             const char* base = smem + buf * TILE_BYTES + mh * (64 * 128);
 #pragma unroll
             for (int mi2 = 0; mi2 < 2; ++mi2)
@@ -501,6 +654,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
                     fa[mi2][ks] = *reinterpret_cast<const bf16x8_t*>(base + la[ks] + mi2 * (32 * 128));
         };
         auto ld_b = [&](int buf, int nh, bf16x8_t (&fb)[4]) {
+            if constexpr ((OTTER_DIAG & 8) != 0) return;
             const char* base = smem + buf * TILE_BYTES + nh * (32 * 128);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const bf16x8_t*>(base + lb[ks]);
@@ -518,7 +672,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < ((OTTER_DIAG & 2) ? 0 : 4); ++ks) {                                    \
             acc[(MH)*2 + 0][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[0][ks], acc[(MH)*2 + 0][NH], 0, 0, 0); \
             acc[(MH)*2 + 1][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FB[ks], FA[1][ks], acc[(MH)*2 + 1][NH], 0, 0, 0); \
         }                                                                                                               \
@@ -530,11 +684,118 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
         } else {
             stage(0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (SCH == 2 || SCH == 4) {
+            if (nk > 1) { stage_ah(1, 1, 0); stage_bh(1, 1, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         if (wr == 1) RAW_BARRIER();  // stagger the second wave row by one barrier
         bf16x8_t fa[2][4], fb[4];
-        if constexpr (CNT) {
+        [[maybe_unused]] bf16x8_t fb1[4];
+        if constexpr ((OTTER_DIAG & 8) != 0) {  // fragments without LDS reads: lane-dependent, non-zero
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                fb[ks] = __builtin_bit_cast(bf16x8_t, uint4{0x3f803f80u + (unsigned)lane, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u});
+                fa[0][ks] = fa[1][ks] = fb[ks];
+                fb1[ks] = fb[ks];
+            }
+        }
+        if constexpr (SCH == 3) {
+            // LOAD-part-only balanced schedule: fb/fb1 resident (phase 3 reads nothing), two DMA pieces per phase:
+            //   phase 0: A_h0(t+1), 1: B_h0(t+1), 2: B_h1(t+1), 3: A_h1(t+1); reads/pieces = 12/2, 4/2, 8/2, 0/2.
+            for (int t = 0; t < nk; ++t) {
+                const int cur = t & 1;
+                const bool more = t + 1 < nk;
+                ld_a(cur, 0, fa);
+                ld_b(cur, 0, fb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_ah(cur ^ 1, t + 1, 0);
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 0, fa, fb);
+                RAW_BARRIER();
+                ld_b(cur, 1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_bh(cur ^ 1, t + 1, 0);
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 1, fa, fb1);
+                RAW_BARRIER();
+                ld_a(cur, 1, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_bh(cur ^ 1, t + 1, 1);
+                RAW_BARRIER();
+                QUAD(1, 1, fa, fb1);
+                RAW_BARRIER();
+                if (more) { stage_ah(cur ^ 1, t + 1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                RAW_BARRIER();
+                QUAD(1, 0, fa, fb);
+                RAW_BARRIER();
+            }
+        } else if constexpr (SCH == 2 || SCH == 4) {
+            // Rebalanced counted schedule.  Both nh fragments of B stay in registers (fb, fb1), so phase 3 reads nothing
+            // from LDS (24 instead of 28 ds_read_b128 per wave per K-tile, and the WAR argument in the header holds
+            // literally); that read-free phase issues the 4 DMA pieces of A_h0,B_h0 of tile t+2 into the buffer tile t
+            // vacated one phase earlier, phase 0 (12 reads) issues none, phases 1 / 2 issue B_h1 / A_h1 of tile t+1:
+            //   ds_read / DMA pieces per phase = 12/0, 4/2, 8/2, 0/4; every half-tile still has 4 phases to land.
+            // In each LOAD part the ds_reads go first and the DMA pieces last, so a wave that queues behind its row's
+            // other waves at the texture-address unit does so with its LDS reads already in flight.
+            for (int t = 0; t < nk; ++t) {
+                const int cur = t & 1;
+                const bool more = t + 1 < nk, more2 = t + 2 < nk;
+                // ---- phase 0: quadrant (0,0) ----
+                ld_a(cur, 0, fa);
+                ld_b(cur, 0, fb);
+                // B_h1(t) (read in phase 1) must have landed; newer: A_h1(t), [A_h0,B_h0](t+1)
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 0, fa, fb);
+                RAW_BARRIER();
+                // ---- phase 1: quadrant (0,1) ----
+                ld_b(cur, 1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_bh(cur ^ 1, t + 1, 1);
+                // A_h1(t) (phase 2); newer: [A_h0,B_h0](t+1), B_h1(t+1)
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 1, fa, fb1);
+                RAW_BARRIER();
+                // ---- phase 2: quadrant (1,1) ----
+                ld_a(cur, 1, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_ah(cur ^ 1, t + 1, 1);
+                RAW_BARRIER();
+                QUAD(1, 1, fa, fb1);
+                RAW_BARRIER();
+                // ---- phase 3: quadrant (1,0), no LDS reads; first half of tile t+2 into the buffer of tile t ----
+                // (every read of tile t was retired by the lgkmcnt(0) of phase 2's cluster, one barrier ago on this row,
+                //  and the other row's issue point is one barrier later still)
+                RAW_BARRIER();
+                if constexpr (SCH == 2) {
+                    if (more2) { stage_ah(cur, t + 2, 0); stage_bh(cur, t + 2, 0); }
+                    QUAD(1, 0, fa, fb);
+                } else {  // SCH 4: one DMA piece in the shadow of each k-step's first MFMA
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int ks = 0; ks < ((OTTER_DIAG & 2) ? 0 : 4); ++ks) {
+                        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks], fa[0][ks], acc[2][0], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more2) { if (ks < 2) stage_ah(cur, t + 2, 0, ks, ks + 1); else stage_bh(cur, t + 2, 0, ks - 2, ks - 1); }
+                        __builtin_amdgcn_sched_barrier(0);
+                        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[ks], fa[1][ks], acc[3][0], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                // [A_h0,B_h0](t+1) (next phase 0); newer: B_h1(t+1), A_h1(t+1), [A_h0,B_h0](t+2)
+                if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                RAW_BARRIER();
+            }
+        } else if constexpr (CNT) {
             for (int t = 0; t < nk; ++t) {
                 const int cur = t & 1;
                 const bool more = t + 1 < nk;
@@ -604,7 +865,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
         float part = 0.f;
         float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = 0; mi < ((OTTER_DIAG & 4) ? 1 : 4); ++mi) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) park_block(blk, acc[mi][ni], lane, ni * 32);
             __builtin_amdgcn_wave_barrier();
@@ -653,7 +914,7 @@ __device__ __forceinline__ float epilogue_stripe128(const GemmArgs& g, float s, 
     return part;
 }
 
-template <int NS, int EPI>
+template <int NS, int EPI, bool BUF>
 __global__ __launch_bounds__(256) void gemm_bf16_ms_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 32, NT = 256;
     constexpr int STAGE = (BM + BN) * BK * 2;  // 32 KB
@@ -672,6 +933,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_ms_kernel(GemmArgs g) {
 
     const bf16_t* pa[CH];
     const bf16_t* pb[CH];
+    uint32_t oa[CH], ob[CH];  // BUF: 32-bit byte offsets against SGPR buffer descriptors
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    if constexpr (BUF) {
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
+    }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int c = i * NT + tid, row = c >> 2, phys = c & 3;
@@ -680,6 +947,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_ms_kernel(GemmArgs g) {
         int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
         pa[i] = A + ga * g.lda + slot * 8;
         pb[i] = B + gb * g.ldb + slot * 8;
+        oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
+        ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
     }
     auto issue_a = [&](int step) {
         const int buf = step % NS;
@@ -687,6 +956,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_ms_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int wbase = buf * STAGE + (i * NT + wave * 64) * 16;
+            if constexpr (BUF)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
+                                                         (int)oa[i], step * (BK * 2), 0, 0);
+            else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + koff),
                                              (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
         }
@@ -697,6 +970,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_ms_kernel(GemmArgs g) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int wbase = buf * STAGE + BM * 64 + (i * NT + wave * 64) * 16;
+            if constexpr (BUF)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
+                                                         (int)ob[i], step * (BK * 2), 0, 0);
+            else
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + koff),
                                              (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
         }
@@ -904,9 +1181,10 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
 int g_debug = 0;
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_F32 = 10 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_F32 = 100 };
 
-int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
+// wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
+int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
     if (ab_dtype == OTTER_F32) return CFG_F32;
     int v = g_variant;
     if (v == 0) {
@@ -915,8 +1193,11 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype) {
         if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = (K >= 8192) ? CFG_MS5 : CFG_PH;
         else v = CFG_128;
     }
-    if ((v == CFG_MS4 || v == CFG_MS5) && (K % 32 != 0)) v = CFG_256_GLDS;
-    if ((v == CFG_PH || v == CFG_PHC) && (K % 64 != 0 || M * K >= (int64_t(1) << 31) || N * K >= (int64_t(1) << 31))) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
+    if ((v == CFG_MS4 || v == CFG_MS5 || v == CFG_MS5B) && (K % 32 != 0)) v = CFG_256_GLDS;
+    if (v == CFG_WS && K % 64 != 0) v = CFG_256;
+    const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB;
+    if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
+    if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
 }
@@ -967,31 +1248,45 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     if (cfg == CFG_128) return launch_one<128, 128, 2, 2, false, EPI>(grid, st, g);
     if (cfg == CFG_256) return launch_one<256, 256, 2, 4, false, EPI>(grid, st, g);
-    if (cfg == CFG_PH || cfg == CFG_PHC) {
+    if (cfg == CFG_WS) {
+        static bool once = false;
         const int smem = 2 * (256 + 256) * 128;
+        if (!once) { int rc = set_smem(gemm_bf16_ws_kernel<EPI>, smem); if (rc) return rc; once = true; }
         unsigned pg = grid.x < 256u ? grid.x : 256u;
-        if (cfg == CFG_PH) {
-            static bool once = false;
-            if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI, false>, smem); if (rc) return rc; once = true; }
-            hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, false>), dim3(pg), dim3(512), smem, st, g);
-        } else {
-            static bool once = false;
-            if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI, true>, smem); if (rc) return rc; once = true; }
-            hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, true>), dim3(pg), dim3(512), smem, st, g);
-        }
+        hipLaunchKernelGGL((gemm_bf16_ws_kernel<EPI>), dim3(pg), dim3(768), smem, st, g);
         return OTTER_OK;
     }
-    if (cfg == CFG_MS4 || cfg == CFG_MS5) {
+    if (cfg == CFG_PH || cfg == CFG_PHC || cfg == CFG_PHB || cfg == CFG_PHCB || cfg == CFG_PHRB || cfg == CFG_PHLB || cfg == CFG_PHIB) {
+        const int smem = 2 * (256 + 256) * 128;
+        unsigned pg = grid.x < 256u ? grid.x : 256u;
+#define LAUNCH_PH(CNT_, BUF_)                                                                                              \
+    do {                                                                                                                   \
+        static bool once = false;                                                                                          \
+        if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI, CNT_, BUF_>, smem); if (rc) return rc; once = true; }      \
+        hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, CNT_, BUF_>), dim3(pg), dim3(512), smem, st, g);                      \
+    } while (0)
+        if (cfg == CFG_PH) LAUNCH_PH(0, false);
+        else if (cfg == CFG_PHC) LAUNCH_PH(1, false);
+        else if (cfg == CFG_PHB) LAUNCH_PH(0, true);
+        else if (cfg == CFG_PHCB) LAUNCH_PH(1, true);
+        else if (cfg == CFG_PHRB) LAUNCH_PH(2, true);
+        else if (cfg == CFG_PHLB) LAUNCH_PH(3, true);
+        else LAUNCH_PH(4, true);
+#undef LAUNCH_PH
+        return OTTER_OK;
+    }
+    if (cfg == CFG_MS4 || cfg == CFG_MS5 || cfg == CFG_MS5B) {
         const int smem = (cfg == CFG_MS4 ? 4 : 5) * 32768;
-        if (cfg == CFG_MS4) {
-            static bool once = false;
-            if (!once) { int rc = set_smem(gemm_bf16_ms_kernel<4, EPI>, smem); if (rc) return rc; once = true; }
-            hipLaunchKernelGGL((gemm_bf16_ms_kernel<4, EPI>), grid, dim3(256), smem, st, g);
-        } else {
-            static bool once = false;
-            if (!once) { int rc = set_smem(gemm_bf16_ms_kernel<5, EPI>, smem); if (rc) return rc; once = true; }
-            hipLaunchKernelGGL((gemm_bf16_ms_kernel<5, EPI>), grid, dim3(256), smem, st, g);
-        }
+#define LAUNCH_MS(NS_, BUF_)                                                                                               \
+    do {                                                                                                                   \
+        static bool once = false;                                                                                          \
+        if (!once) { int rc = set_smem(gemm_bf16_ms_kernel<NS_, EPI, BUF_>, smem); if (rc) return rc; once = true; }       \
+        hipLaunchKernelGGL((gemm_bf16_ms_kernel<NS_, EPI, BUF_>), grid, dim3(256), smem, st, g);                           \
+    } while (0)
+        if (cfg == CFG_MS4) LAUNCH_MS(4, false);
+        else if (cfg == CFG_MS5) LAUNCH_MS(5, false);
+        else LAUNCH_MS(5, true);
+#undef LAUNCH_MS
         return OTTER_OK;
     }
     return launch_one<256, 256, 2, 4, true, EPI>(grid, st, g);
@@ -1024,7 +1319,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 7) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 14) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }
@@ -1074,7 +1369,9 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
         default:
             OTTER_FAIL(OTTER_ERR_ARG, "gemm: unknown epilogue %d", g.kind);
     }
-    const int cfg = pick_cfg(M, N, K, ab_dtype);
+    const int64_t esz = ab_dtype == OTTER_BF16 ? 2 : 4;
+    const bool wide = ((M - 1) * lda + K) * esz >= (int64_t(1) << 32) || ((N - 1) * ldb + K) * esz >= (int64_t(1) << 32);
+    const int cfg = pick_cfg(M, N, K, ab_dtype, wide);
     int bm, bn;
     cfg_tiles(cfg, bm, bn);
     g.dbg = g_debug;

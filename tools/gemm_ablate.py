@@ -1,8 +1,12 @@
-"""Ablation of the bf16 GEMM at the FFN shape: full vs no-global-loads vs no-MFMA (diagnostic flags; wrong results)."""
-import json, os, sys
+"""Ablation of the phased bf16 GEMM at the FFN shape with the compile-time diagnostics builds (results are wrong by
+construction; timing only).  Usage: gemm_ablate.py [variant] -- run once per build, e.g.
+    for m in 0 1 2 3 4 8 9 10; do python -m otter_amd.build --diag $m; done            (here, cross-compiled)
+    for m in 0 1 2 3 4 8 9 10; do OTTER_LIB_PATH=otter_amd/lib/libotter_hip_diag$m.so python tools/gemm_ablate.py 10; done
+mask bits: 1 = no DMA, 2 = no MFMA, 4 = no epilogue (one stripe of four), 8 = no LDS fragment reads."""
+import json, os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from otter_amd import ops, _capi
+from otter_amd import ops
 
 def bench(fn, iters=10):
     fn(); torch.cuda.synchronize()
@@ -10,21 +14,16 @@ def bench(fn, iters=10):
     s.record()
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / iters
+    return s.elapsed_time(e) / iters * 1e3
 
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 M, N, K = 4096, 16384, 4096
 A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
 C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-for v in (3,):
-    ops.set_gemm_variant(v)
-    row = {"variant": v}
-    for name, flag in (("full", 0), ("noload", 1), ("nomfma", 2), ("neither", 3), ("noepi", 4), ("nokloop", 8), ("nothing", 12), ("nostores", 16), ("nokloop_nostores", 24)):
-        _capi.lib().otter_gemm_set_debug(flag)
-        ms = bench(lambda: ops.gemm_nt(A, B, out=C))
-        row[name + "_us"] = round(ms * 1e3, 1)
-    _capi.lib().otter_gemm_set_debug(0)
-    row["full_TF"] = round(2 * M * N * K / row["full_us"] / 1e6, 1)
-    row["noload_TF_equiv"] = round(2 * M * N * K / row["noload_us"] / 1e6, 1)
-    print(json.dumps(row), flush=True)
+ops.set_gemm_variant(variant)
+us = [bench(lambda: ops.gemm_nt(A, B, out=C)) for _ in range(3)]
 ops.set_gemm_variant(0)
+print(json.dumps({"lib": os.path.basename(os.environ.get("OTTER_LIB_PATH") or "libotter_hip.so"), "variant": variant,
+                  "us_med": round(statistics.median(us), 1), "us_min": round(min(us), 1),
+                  "TF_equiv": round(2 * M * N * K / statistics.median(us) / 1e6, 1)}), flush=True)
