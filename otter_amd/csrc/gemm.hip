@@ -135,6 +135,15 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
 // demoted the accumulators to scratch; an out-of-line body took its arguments through flat (generic) pointers.
 constexpr int EPI_LD = 68;  // floats per parked row (64 + 4 pad; rows stay 16-B aligned)
 
+// Compile-time diagnostics for the ablation builds of tools/gemm_ablate.py (`python -m otter_amd.build --diag N` writes
+// lib/libotter_hip_diagN.so; results are WRONG by construction).  Phased kernel only: 1 = no DMA, 2 = no MFMA,
+// 4 = epilogue without its global loads/stores, 8 = no ds_read of fragments, 16 = no epilogue at all (accumulators are
+// only summed so that the MFMAs stay live), 32 = half the A-fragment reads, 64 = half the DMA pieces.  Compile-time on purpose: a runtime flag inside the K-loop lambdas cost the
+// product kernels 3-4x.
+#ifndef OTTER_DIAG
+#define OTTER_DIAG 0
+#endif
+
 template <int EPI>
 __device__ __forceinline__ float epilogue_stripe(const GemmArgs& g, float s, const float* __restrict__ blk, int64_t m_base,
                                                  int64_t n_base, int lane) {
@@ -147,7 +156,7 @@ __device__ __forceinline__ float epilogue_stripe(const GemmArgs& g, float s, con
         if (m < g.M && n < g.N) {
             const float4 t = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
             float v[4] = {t.x, t.y, t.z, t.w};
-            if (g.dbg & 16) {  // diagnostics: everything but the global traffic of the tail
+            if ((OTTER_DIAG & 4) || (g.dbg & 16)) {  // diagnostics: everything but the global traffic of the tail
                 part += v[0] + v[1] + v[2] + v[3];
             } else {
                 part += epilogue4<EPI>(g, s, m, n, v);
@@ -511,12 +520,6 @@ __global__ __launch_bounds__(768) void gemm_bf16_ws_kernel(GemmArgs g) {
 //        registers) and phase 2's reads are retired by lgkmcnt(0) before its MFMAs, so when any wave issues the DMA in
 //        phase 0 of tile t every read of tile t-1 has completed, on both rows.
 // ------------------------------------------------------------------------------------------------------------
-// Compile-time diagnostics for the ablation builds of tools/gemm_ablate.py (`python -m otter_amd.build --diag N` writes
-// lib/libotter_hip_diagN.so; results are WRONG by construction): 1 = no DMA, 2 = no MFMA, 4 = no epilogue, 8 = no ds_read.
-// Compile-time on purpose: a runtime flag inside these lambdas costs the product kernels 3-4x (section 4.1 of DESIGN.md).
-#ifndef OTTER_DIAG
-#define OTTER_DIAG 0
-#endif
 template <int EPI, int SCH, bool BUF>
 __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
     constexpr bool CNT = SCH >= 1;
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
             if constexpr ((OTTER_DIAG & 1) != 0) return;
             const char* abase = reinterpret_cast<const char*>(A) + (size_t)kt * 128;
 #pragma unroll
-            for (int i = i0; i < i1; ++i) {
+            for (int i = i0; i < ((OTTER_DIAG & 64) ? (i1 < 1 ? i1 : 1) : i1); ++i) {  // diag 64: half the DMA pieces
                 const int wbase = buf * TILE_BYTES + (i * 128 + h * 64 + wave * 8) * 128;
                 if constexpr (BUF)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
             if constexpr ((OTTER_DIAG & 1) != 0) return;
             const char* bbase = reinterpret_cast<const char*>(B) + (size_t)kt * 128;
 #pragma unroll
-            for (int i = i0; i < i1; ++i) {
+            for (int i = i0; i < ((OTTER_DIAG & 64) ? (i1 < 1 ? i1 : 1) : i1); ++i) {
                 const int wbase = buf * TILE_BYTES + BM * 128 + ((2 * i + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8) * 128;
                 if constexpr (BUF)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
@@ -648,10 +651,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
             if constexpr ((OTTER_DIAG & 8) != 0) return;
             const char* base = smem + buf * TILE_BYTES + mh * (64 * 128);
 #pragma unroll
-            for (int mi2 = 0; mi2 < 2; ++mi2)
+            for (int mi2 = 0; mi2 < ((OTTER_DIAG & 32) ? 1 : 2); ++mi2)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
                     fa[mi2][ks] = *reinterpret_cast<const bf16x8_t*>(base + la[ks] + mi2 * (32 * 128));
+            if constexpr ((OTTER_DIAG & 32) != 0) {  // half the A fragment reads
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) fa[1][ks] = fa[0][ks];
+            }
         };
         auto ld_b = [&](int buf, int nh, bf16x8_t (&fb)[4]) {
             if constexpr ((OTTER_DIAG & 8) != 0) return;
@@ -687,6 +694,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
         if constexpr (SCH == 2 || SCH == 4) {
             if (nk > 1) { stage_ah(1, 1, 0); stage_bh(1, 1, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (SCH == 6) {
+            if (nk > 1) {
+                stage_ah(1, 1, 0); stage_bh(1, 1, 0); stage_bh(1, 1, 1); stage_ah(1, 1, 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -702,7 +716,82 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
                 fb1[ks] = fb[ks];
             }
         }
-        if constexpr (SCH == 3) {
+        if constexpr (SCH == 6) {
+            // Deep-queue schedule: every half-tile slot is refilled ONE phase after its only read, with the data of tile
+            // t+2 (same buffer), instead of one K-tile later with tile t+1's -- 10-12 DMA pieces per wave in flight
+            // instead of 4-6 (the L2->LDS stream is latency x concurrency bound: DESIGN.md 4.1).
+            //   reads  : phase 0: A_h0,B_h0   1: B_h1   2: A_h1   3: -          (B fragments stay in fb / fb1)
+            //   refill : phase 1: A_h0(t+2)   2: B_h0(t+2)   3: B_h1(t+2), A_h1(t+2)   (ds_read / DMA = 12/0 4/2 8/2 0/4)
+            // WAR: fragment reads are retired (lgkmcnt(0)) BEFORE the first barrier of their phase; the other row passes
+            // the matching barrier before its next LOAD part, so a refill issued one phase later can never overtake a read.
+            // RAW: counted vmcnt in the phase before the read, before that phase's first barrier (as in the other schedules).
+            for (int t = 0; t < nk; ++t) {
+                const int cur = t & 1;
+                const int e = nk - 1 - t;  // K-tiles after this one
+                // ---- phase 0: quadrant (0,0) ----
+                ld_a(cur, 0, fa);
+                ld_b(cur, 0, fb);
+                if (e >= 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 0, fa, fb);
+                RAW_BARRIER();
+                // ---- phase 1: quadrant (0,1) ----
+                ld_b(cur, 1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (e >= 2) { stage_ah(cur, t + 2, 0); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+                else if (e == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 1, fa, fb1);
+                RAW_BARRIER();
+                // ---- phase 2: quadrant (1,1) ----
+                ld_a(cur, 1, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (e >= 2) stage_bh(cur, t + 2, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(1, 1, fa, fb1);
+                RAW_BARRIER();
+                // ---- phase 3: quadrant (1,0) ----
+                if (e >= 2) { stage_bh(cur, t + 2, 1); stage_ah(cur, t + 2, 1); asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+                else if (e == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(1, 0, fa, fb);
+                RAW_BARRIER();
+            }
+        } else if constexpr (SCH == 5) {
+            // Two phases per K-tile (16 MFMAs per cluster, 4 workgroup barriers per K-tile instead of 8):
+            //   phase A: reads A0,B0,B1 (16) + 6 DMA pieces [A_h0,B_h0,B_h1](t+1) | quadrants (0,0),(0,1)
+            //   phase B: reads A1 (8)       + 2 DMA pieces  A_h1(t+1)            | quadrants (1,1),(1,0)
+            // The fragment reads are retired (lgkmcnt(0)) BEFORE the first barrier of their phase, so once a row has
+            // passed that barrier none of its reads of the buffer is pending: the other row may refill it right away.
+            for (int t = 0; t < nk; ++t) {
+                const int cur = t & 1;
+                const bool more = t + 1 < nk;
+                ld_a(cur, 0, fa);
+                ld_b(cur, 0, fb);
+                ld_b(cur, 1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { stage_ah(cur ^ 1, t + 1, 0); stage_bh(cur ^ 1, t + 1, 0); stage_bh(cur ^ 1, t + 1, 1); }
+                // A_h1(t) (read in phase B); newer: the 6 pieces just issued
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(0, 0, fa, fb);
+                QUAD(0, 1, fa, fb1);
+                RAW_BARRIER();
+                ld_a(cur, 1, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { stage_ah(cur ^ 1, t + 1, 1); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RAW_BARRIER();
+                QUAD(1, 1, fa, fb1);
+                QUAD(1, 0, fa, fb);
+                RAW_BARRIER();
+            }
+        } else if constexpr (SCH == 3) {
             // LOAD-part-only balanced schedule: fb/fb1 resident (phase 3 reads nothing), two DMA pieces per phase:
             //   phase 0: A_h0(t+1), 1: B_h0(t+1), 2: B_h1(t+1), 3: A_h1(t+1); reads/pieces = 12/2, 4/2, 8/2, 0/2.
             for (int t = 0; t < nk; ++t) {
@@ -865,12 +954,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
         float part = 0.f;
         float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
 #pragma unroll
-        for (int mi = 0; mi < ((OTTER_DIAG & 4) ? 1 : 4); ++mi) {
+        for (int mi = 0; mi < 4; ++mi) {
+            if constexpr ((OTTER_DIAG & 16) != 0) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part += acc[mi][ni][r];
+                continue;
+            }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) park_block(blk, acc[mi][ni], lane, ni * 32);
             __builtin_amdgcn_wave_barrier();
             part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wr * 128 + mi * 32, n0 + wc * 64, lane);
             __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr ((OTTER_DIAG & 20) != 0) {  // keep `part` (hence the accumulators) observable
+            if (part == 12345.678f) reinterpret_cast<float*>(g.C)[threadIdx.x] = part;
         }
         block_partial<8, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
         __syncthreads();
@@ -1181,21 +1280,21 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
 int g_debug = 0;
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_F32 = 100 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
     if (ab_dtype == OTTER_F32) return CFG_F32;
     int v = g_variant;
     if (v == 0) {
-        // interleaved A/B medians on MI355X (tools/gemm_ab.py): the phased/staggered schedule wins at K = 4096
-        // (1082 / 1136 TF vs 967 / 1063 for the 2-phase kernel), the 5-stage one-wave-per-SIMD ring at K = 16384 (1183 vs 1123)
-        if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = (K >= 8192) ? CFG_MS5 : CFG_PH;
+        // interleaved A/B medians on MI355X (tools/gemm_ab.py): the balanced phased schedule with buffer
+        // addressing wins on all three FFN shapes (1.31-1.41 PF vs 1.16-1.34 for variant 10, 1.10-1.22 for the ring)
+        if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = CFG_PHLB;
         else v = CFG_128;
     }
     if ((v == CFG_MS4 || v == CFG_MS5 || v == CFG_MS5B) && (K % 32 != 0)) v = CFG_256_GLDS;
     if (v == CFG_WS && K % 64 != 0) v = CFG_256;
-    const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB;
+    const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB || v == CFG_PH2B || v == CFG_PHDB;
     if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
     if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
@@ -1256,7 +1355,7 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         hipLaunchKernelGGL((gemm_bf16_ws_kernel<EPI>), dim3(pg), dim3(768), smem, st, g);
         return OTTER_OK;
     }
-    if (cfg == CFG_PH || cfg == CFG_PHC || cfg == CFG_PHB || cfg == CFG_PHCB || cfg == CFG_PHRB || cfg == CFG_PHLB || cfg == CFG_PHIB) {
+    if (cfg == CFG_PH || cfg == CFG_PHC || cfg == CFG_PHB || cfg == CFG_PHCB || cfg == CFG_PHRB || cfg == CFG_PHLB || cfg == CFG_PHIB || cfg == CFG_PH2B || cfg == CFG_PHDB) {
         const int smem = 2 * (256 + 256) * 128;
         unsigned pg = grid.x < 256u ? grid.x : 256u;
 #define LAUNCH_PH(CNT_, BUF_)                                                                                              \
@@ -1271,7 +1370,9 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         else if (cfg == CFG_PHCB) LAUNCH_PH(1, true);
         else if (cfg == CFG_PHRB) LAUNCH_PH(2, true);
         else if (cfg == CFG_PHLB) LAUNCH_PH(3, true);
-        else LAUNCH_PH(4, true);
+        else if (cfg == CFG_PHIB) LAUNCH_PH(4, true);
+        else if (cfg == CFG_PH2B) LAUNCH_PH(5, true);
+        else LAUNCH_PH(6, true);
 #undef LAUNCH_PH
         return OTTER_OK;
     }
@@ -1319,7 +1420,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 14) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 16) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }

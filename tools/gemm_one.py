@@ -9,8 +9,12 @@ M, N, K = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (4096, 16384
 A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
 B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
 C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-ops.set_gemm_variant(v)
+if v >= 0:
+    ops.set_gemm_variant(v)
 for _ in range(it):
-    ops.gemm_nt(A, B, out=C)
+    if v >= 0:
+        ops.gemm_nt(A, B, out=C)
+    else:  # hipBLASLt through torch, for side-by-side counter passes
+        torch.matmul(A, B.t(), out=C)
 torch.cuda.synchronize()
 print("done", v, it, M, N, K)
