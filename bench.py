@@ -227,7 +227,7 @@ def main():
             if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
                 with open(pmc) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_kernel<256,256> M=%d N=%d K=%d" % (M, N, Kd), "achieved": round(ach, 1),
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves) M=%d N=%d K=%d" % (M, N, Kd), "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
         out = {

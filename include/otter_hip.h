@@ -175,6 +175,41 @@ int otter_attn_bwd(const void* q, int64_t q_stride, const void* k, const void* v
                    int64_t Tq, int64_t M, int64_t n_per_media, int mask_mode, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Flash attention of the frozen decoder host, head_dim 128, bf16, MFMA:
+ *   scaled_multihead_dot_product_attention   /root/reference/src/otter_ai/models/mpt/attention.py:22-84
+ *   ALiBi bias (key-position form)           .../mpt/attention.py:447-464      bias[h,j] = slope[h] * (j - (Sk-1))
+ *   key-padding mask                         .../mpt/modeling_mpt.py:135-144
+ *   causal mask                              .../mpt/attention.py:64-72        key j visible to query i iff j <= i + Sk - Sq
+ * out = softmax(scale * q k^T + bias + masks) v without materialising the scores; the bias is evaluated in fp32 in
+ * the kernel.  q/k/v/o (and the gradients) are [B, S, H, 128] views given by element strides, so the three slices
+ * of a fused Wqkv output and of its gradient buffer are addressed in place (no chunk/cat copies).
+ * lse [B,H,Sq] fp32 (natural log) is written by the forward and read by the backward; delta [B,H,Sq] fp32 is
+ * backward workspace.  A query row with no visible key yields 0 (lse = -inf) and zero gradients; the reference's
+ * masked_fill(finfo.min) would yield the uniform average there -- such rows only exist for left-padded prompts,
+ * which the host routes to its SDPA path.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct otter_flash_view {
+    int64_t batch_stride, seq_stride, head_stride; /* in elements; multiples of 8 */
+} otter_flash_view;
+
+typedef struct otter_flash_desc {
+    const void* q; const void* k; const void* v; otter_flash_view qv, kv, vv;
+    void* o; otter_flash_view ov;
+    float* lse;
+    const float* alibi_slopes;   /* [H] fp32 or NULL */
+    const uint8_t* key_valid;    /* [B, Sk] (0 = padded key) or NULL */
+    int B, H, Sq, Sk, head_dim, causal;
+    float scale;
+    /* backward only */
+    const void* dout; otter_flash_view dov;
+    float* delta;
+    void* dq; void* dk; void* dv; otter_flash_view dqv, dkv, dvv;
+} otter_flash_desc;
+
+int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream);
+int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * RoPE, half-split (non-interleaved) layout, optional partial rotary.  Replaces
  * /root/reference/xformers_model/llama.py:158-166 (config C4) and flash_attn apply_rotary_emb at
  * fuyu/modeling_persimmon.py:303-304 (config C5).  x [B,S,H,d]; cos/sin fp32 [S, rot_dim]; in place allowed.

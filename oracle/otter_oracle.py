@@ -368,6 +368,31 @@ def mpt_attn_bias(n_heads, s_k, total_len, alibi_bias_max=8, dtype=np.float32):
     return (pos[None, None, None, :] * alibi_slopes(n_heads, alibi_bias_max)[None, :, None, None]).astype(dtype)
 
 
+def mpt_attention_core(qh, kh, vh, scale, slopes=None, key_padding=None, causal=True, dctx=None):
+    """The attention core of mpt/attention.py:22-84 on split heads [B,h,S,d] with the ALiBi bias of :447-464 built in its
+    key-position form (slope * (j - (Sk-1))), key padding as masked_fill(finfo.min) (modeling_mpt.py:135-144) and the
+    causal triangle (attention.py:64-72).  Returns ctx [B,h,Sq,d] and, when dctx is given, (dq, dk, dv)."""
+    s_q, s_k = qh.shape[2], kh.shape[2]
+    w = (qh @ np.swapaxes(kh, -1, -2)) * scale
+    if slopes is not None:
+        w = w + (np.asarray(slopes, w.dtype)[None, :, None, None] * np.arange(1 - s_k, 1, dtype=w.dtype)[None, None, None, :])
+    minv = np.finfo(w.dtype).min
+    if key_padding is not None:
+        w = np.where(key_padding[:, None, None, -s_k:].astype(bool), w, minv)
+    if causal and s_q != 1:
+        s = max(s_q, s_k)
+        cm = ~np.tril(np.ones((s, s), dtype=bool))[-s_q:, -s_k:]
+        w = np.where(cm[None, None], minv, w)
+    pr = softmax_lastdim(w)
+    ctx = pr @ vh
+    if dctx is None:
+        return ctx
+    dvh = np.swapaxes(pr, -1, -2) @ dctx
+    dpr = dctx @ np.swapaxes(vh, -1, -2)
+    dw = pr * (dpr - (dpr * pr).sum(-1, keepdims=True)) * scale
+    return ctx, (dw @ kh, np.swapaxes(dw, -1, -2) @ qh, dvh)
+
+
 def mpt_block_fwd(p, pre, x, n_heads, attn_bias, key_padding=None, past_kv=None):
     """Pre-LN block, fused Wqkv, causal softmax attention with additive bias.  blocks.py:68-88, attention.py:22-84.
     past_kv = (k_past [B,h,d,S0], v_past [B,h,S0,d]) as in the reference's torch cache layout."""

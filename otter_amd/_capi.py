@@ -37,6 +37,25 @@ class EpilogueArgs(C.Structure):
     ]
 
 
+class FlashView(C.Structure):
+    _fields_ = [("batch_stride", C.c_int64), ("seq_stride", C.c_int64), ("head_stride", C.c_int64)]
+
+
+class FlashDesc(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("qv", FlashView), ("kv", FlashView), ("vv", FlashView),
+        ("o", C.c_void_p), ("ov", FlashView),
+        ("lse", C.c_void_p),
+        ("alibi_slopes", C.c_void_p),
+        ("key_valid", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("Sq", C.c_int), ("Sk", C.c_int), ("head_dim", C.c_int), ("causal", C.c_int),
+        ("scale", C.c_float),
+        ("dout", C.c_void_p), ("dov", FlashView),
+        ("delta", C.c_void_p),
+        ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p), ("dqv", FlashView), ("dkv", FlashView), ("dvv", FlashView),
+    ]
+
+
 _i64, _int, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes): exactly the declarations of include/otter_hip.h (tests/test_capi_symbols.py checks this)
@@ -68,6 +87,8 @@ SIGNATURES = {
     "otter_rope": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
     "otter_add_frame_embs": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _i64, _vp]),
     "otter_add_rows": (_int, [_vp, _vp, RowMap, _i64, _i64, _int, _vp]),
+    "otter_flash_attn_fwd": (_int, [C.POINTER(FlashDesc), _vp]),
+    "otter_flash_attn_bwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_prof_arm_gemm": (_int, [_i64, _i64, _i64, _int]),
     "otter_prof_disarm": (_int, []),
     "otter_prof_collect": (_int, [C.POINTER(_int), C.POINTER(C.c_double)]),

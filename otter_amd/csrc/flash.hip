@@ -1,0 +1,548 @@
+// flash.hip -- MFMA flash attention (forward, dQ, dK+dV) for the frozen decoder host, head_dim 128, bf16 in / fp32 math.
+//
+// Replaces, for the training / prefill case, the reference's `scaled_multihead_dot_product_attention`
+// (mpt/attention.py:22-84: q k^T * softmax_scale + attn_bias, causal mask, softmax, . v) together with the ALiBi bias of
+// mpt/attention.py:447-464 and the key-padding mask of modeling_mpt.py:135-144 -- without materialising the [B,H,S,S]
+// scores, and with the bias evaluated in fp32 inside the kernel:  bias[h, j] = slope[h] * (j - (Sk - 1)).
+//
+// Orientation (gfx950, wave64, v_mfma_f32_32x32x16_bf16; operand A: lane l = row l&31, k-elements 8(l>>5)..+7;
+// operand B: lane l = column l&31, same k-elements; C: lane l = column l&31, rows (r&3) + 8(r>>2) + 4(l>>5)):
+//   forward / dQ : S^T = K Q^T, so a lane owns ONE query (its column) and 16 keys per 32-key block: the softmax row
+//                  statistics (max, sum, LSE, delta) are lane-local scalars, one cross-half exchange per tile.  The C
+//                  registers of P^T / dS^T are, as they stand, the B operand of the second product (contraction over
+//                  keys): O^T = V^T P^T, dQ^T = K^T dS^T.  Its A operand (V^T / K^T: row = d, k = keys) is read from the
+//                  row-major [key][d] LDS tile with the hardware transpose read ds_read_b64_tr_b16.
+//   dK / dV      : S = Q K^T, so a lane owns ONE key and 16 queries: P / dS registers are the B operand of the products
+//                  that contract over queries, dV^T = dO^T P, dK^T = Q^T dS, whose A operands (row = d, k = queries) are
+//                  transpose-read from the [query][d] tiles; K and V fragments of the wave's 32 keys stay in registers.
+// The k-dimension of the second products runs over the C-register order (element j of half h of chunk c is row
+// 16c + 4h + (j&3) + 8(j>>2)); the transpose reads fetch their rows in the same order, so no data is ever permuted.
+// LDS tiles read with ds_read_b128 use 272-B rows, tiles read with the transpose read use 320-B rows (both conflict-free
+// for their access pattern: 16 rows x one 16-B slot, resp. 4 rows x 64 B per 32 lanes); a tile needed both ways is
+// stored twice.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+constexpr int HD = 128;       // head dim
+constexpr int LDK = HD + 8;   // row-fragment tiles (272-B rows)
+constexpr int LDT = HD + 32;  // transpose-read tiles (320-B rows)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct Str { int64_t b, s, h; };  // element strides of a [B, S, H, 128] view
+
+struct FlashArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; Str qs, ks, vs;
+    bf16_t* o; Str os;
+    float* lse;            // [B, H, Sq] natural-log LSE
+    const float* slopes;   // [H] or null
+    const uint8_t* kvalid; // [B, Sk] or null
+    int B, H, Sq, Sk, causal;
+    float scale;
+    const bf16_t* dout; Str dos;
+    float* delta;          // [B, H, Sq]
+    bf16_t* dq; bf16_t* dk; bf16_t* dv; Str dqs, dks, dvs;
+};
+
+__device__ __forceinline__ f32x16_t zero16() {
+    f32x16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// A operand [32 rows d x 16 k] out of a row-major [k][d] tile with 320-B rows; p already includes the per-lane part
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* p) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 8 * LDT));
+    const s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+// per-lane offset of the transpose read: lane i of a 16-lane group supplies row (i>>2), columns 4(i&3)..+3 of the
+// [4][16] block; groups 0/1 take d-columns 0-15 / 16-31 of the 32-wide d block, groups 2/3 the rows of half h = 1
+__device__ __forceinline__ int tr_lane_off(int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    return (4 * (g >> 1) + (i >> 2)) * LDT + 16 * (g & 1) + 4 * (i & 3);
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& x, int r0) {
+    bf16x8_t r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (__bf16)x[r0 + j];
+    return r;
+}
+
+// store the C registers of a [d, row] block product as row-major [row][d] bf16: lane = row, 4 consecutive d per r-group
+__device__ __forceinline__ void store_dt(bf16_t* rowp, const f32x16_t (&acc)[4], float mul, int h2) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
+            w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(rowp + 32 * db + 8 * g + 4 * h2) = w;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// forward: grid (ceil(Sq/128), H, B), 4 waves, wave w owns queries q0 + 32w .. +31; key tiles of 64
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);  // [64][LDK]
+    bf16_t* Vt = Ks + 64 * LDK;                    // [64][LDT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128;
+    const int qi = q0 + wave * 32 + ql;
+    const int off = a.Sk - a.Sq;
+    const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)(qi < a.Sq ? qi : a.Sq - 1) * a.qs.s;
+    bf16x8_t qf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2);
+    const bf16_t* kb = a.k + b * a.ks.b + hd * a.ks.h;
+    const bf16_t* vb = a.v + b * a.vs.b + hd * a.vs.h;
+    const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    int nkt = (a.Sk + 63) >> 6;
+    if (a.causal) {
+        const int qmax = (q0 + 127 < a.Sq ? q0 + 127 : a.Sq - 1) + off;
+        const int lim = qmax < 0 ? 0 : (qmax >> 6) + 1;
+        nkt = nkt < lim ? nkt : lim;
+    }
+    uint4 kr[4], vr[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i, row = ch >> 4, c16 = ch & 15, key = kt * 64 + row;
+            if (key < a.Sk) {
+                kr[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * a.ks.s + c16 * 8);
+                vr[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * a.vs.s + c16 * 8);
+            } else {
+                kr[i] = make_uint4(0, 0, 0, 0);
+                vr[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i, row = ch >> 4, c16 = ch & 15;
+            *reinterpret_cast<uint4*>(Ks + row * LDK + c16 * 8) = kr[i];
+            *reinterpret_cast<uint4*>(Vt + row * LDT + c16 * 8) = vr[i];
+        }
+    };
+    const int troff = tr_lane_off(lane);
+    float m = -INFINITY, lsum = 0.f;
+    f32x16_t o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = zero16();
+    if (nkt > 0) gload(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        swrite();
+        __syncthreads();
+        if (kt + 1 < nkt) gload(kt + 1);
+        const int k0 = kt * 64;
+        if (a.causal && k0 > q0 + wave * 32 + 31 + off) continue;  // whole tile above this wave's diagonal
+        f32x16_t s[2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            s[kbk] = zero16();
+            const bf16_t* rowp = Ks + (32 * kbk + ql) * LDK + 8 * h2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(rowp + 16 * c), qf[c], s[kbk], 0, 0, 0);
+        }
+        // element (kbk, r) is key k0 + cidx + 4 h2 with the compile-time cidx = 32 kbk + (r&3) + 8 (r>>2): causal / length
+        // limits, the ALiBi ramp and the key-validity bit are all "constant + per-tile lane scalar"
+        const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
+        const int limh = (a.causal && rel < kend ? rel : kend) - 4 * h2;
+        const float base = sl2 * (float)(k0 + 4 * h2 - (a.Sk - 1));
+        unsigned long long vmh = ~0ull;
+        if (kv) {
+            const int jj = k0 + lane;
+            vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                float x = fmaf(s[kbk][r], sc2, fmaf(sl2, (float)cidx, base));
+                const bool ok = cidx <= limh && ((vmh >> cidx) & 1ull);
+                x = ok ? x : -INFINITY;
+                s[kbk][r] = x;
+                mx = fmaxf(mx, x);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float muse = mnew == -INFINITY ? 0.f : mnew;
+        const float alpha = __builtin_amdgcn_exp2f(m - muse);
+        m = mnew;
+        lsum *= alpha;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kbk][r] - muse);
+                s[kbk][r] = p;
+                lsum += p;
+            }
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8_t pf = pack8(s[kbk], 8 * c);
+                const bf16_t* tp = Vt + troff + (32 * kbk + 16 * c) * LDT;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tp + 32 * db), pf, o[db], 0, 0, 0);
+            }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    if (qi < a.Sq) {
+        store_dt(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s, o, inv, h2);
+        if (h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// delta[b,h,q] = sum_d dO . O   (16 lanes per row)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = threadIdx.x & 15;
+    const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
+    float acc = 0.f;
+    if (row < nrows) {
+        const int qi = (int)(row % a.Sq);
+        const int hd = (int)((row / a.Sq) % a.H);
+        const int b = (int)(row / ((int64_t)a.Sq * a.H));
+        float x[8], y[8];
+        Vec8<bf16_t>::load(a.dout + b * a.dos.b + hd * a.dos.h + (int64_t)qi * a.dos.s + 8 * c, x);
+        Vec8<bf16_t>::load(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s + 8 * c, y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += x[i] * y[i];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (row < nrows && c == 0) a.delta[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dQ: same decomposition as the forward; per key tile  S^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);  // [64][LDK]
+    bf16_t* Vs = Ks + 64 * LDK;                    // [64][LDK]
+    bf16_t* Kt = Vs + 64 * LDK;                    // [64][LDT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128;
+    const int qi = q0 + wave * 32 + ql;
+    const int qc = qi < a.Sq ? qi : a.Sq - 1;
+    const int off = a.Sk - a.Sq;
+    const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)qc * a.qs.s;
+    const bf16_t* dop = a.dout + b * a.dos.b + hd * a.dos.h + (int64_t)qc * a.dos.s;
+    bf16x8_t qf[8], dof[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2);
+        dof[c] = *reinterpret_cast<const bf16x8_t*>(dop + 16 * c + 8 * h2);
+    }
+    const int64_t srow = ((int64_t)b * a.H + hd) * a.Sq + qc;
+    const float lse_n = a.lse[srow];
+    const bool live = qi < a.Sq && lse_n != -INFINITY;
+    const float lse2 = lse_n * LOG2E, dl = a.delta[srow];
+    const bf16_t* kb = a.k + b * a.ks.b + hd * a.ks.h;
+    const bf16_t* vb = a.v + b * a.vs.b + hd * a.vs.h;
+    const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    int nkt = (a.Sk + 63) >> 6;
+    if (a.causal) {
+        const int qmax = (q0 + 127 < a.Sq ? q0 + 127 : a.Sq - 1) + off;
+        const int lim = qmax < 0 ? 0 : (qmax >> 6) + 1;
+        nkt = nkt < lim ? nkt : lim;
+    }
+    uint4 kr[4], vr[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i, row = ch >> 4, c16 = ch & 15, key = kt * 64 + row;
+            if (key < a.Sk) {
+                kr[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * a.ks.s + c16 * 8);
+                vr[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * a.vs.s + c16 * 8);
+            } else {
+                kr[i] = make_uint4(0, 0, 0, 0);
+                vr[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i, row = ch >> 4, c16 = ch & 15;
+            *reinterpret_cast<uint4*>(Ks + row * LDK + c16 * 8) = kr[i];
+            *reinterpret_cast<uint4*>(Kt + row * LDT + c16 * 8) = kr[i];
+            *reinterpret_cast<uint4*>(Vs + row * LDK + c16 * 8) = vr[i];
+        }
+    };
+    const int troff = tr_lane_off(lane);
+    f32x16_t dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = zero16();
+    if (nkt > 0) gload(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        swrite();
+        __syncthreads();
+        if (kt + 1 < nkt) gload(kt + 1);
+        const int k0 = kt * 64;
+        if (a.causal && k0 > q0 + wave * 32 + 31 + off) continue;
+        const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
+        const int limh = live ? (a.causal && rel < kend ? rel : kend) - 4 * h2 : -1;
+        const float base = sl2 * (float)(k0 + 4 * h2 - (a.Sk - 1));
+        unsigned long long vmh = ~0ull;
+        if (kv) {
+            const int jj = k0 + lane;
+            vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
+        }
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            f32x16_t s = zero16(), dp = zero16();
+            const bf16_t* krow = Ks + (32 * kbk + ql) * LDK + 8 * h2;
+            const bf16_t* vrow = Vs + (32 * kbk + ql) * LDK + 8 * h2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(krow + 16 * c), qf[c], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(vrow + 16 * c), dof[c], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                const float x = fmaf(s[r], sc2, fmaf(sl2, (float)cidx, base));
+                const bool ok = cidx <= limh && ((vmh >> cidx) & 1ull);
+                const float p = ok ? __builtin_amdgcn_exp2f(x - lse2) : 0.f;
+                s[r] = p * (dp[r] - dl);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8_t dsf = pack8(s, 8 * c);
+                const bf16_t* tp = Kt + troff + (32 * kbk + 16 * c) * LDT;
+#pragma unroll
+                for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tp + 32 * db), dsf, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < a.Sq) store_dt(a.dq + b * a.dqs.b + hd * a.dqs.h + (int64_t)qi * a.dqs.s, dq, a.scale, h2);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dK, dV: grid (ceil(Sk/128), H, B), wave w owns keys k0 + 32w .. +31 (K, V fragments in registers); query tiles of 32
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);  // [32][LDK]
+    bf16_t* dOs = Qs + 32 * LDK;                   // [32][LDK]
+    bf16_t* Qt = dOs + 32 * LDK;                   // [32][LDT]
+    bf16_t* dOt = Qt + 32 * LDT;                   // [32][LDT]
+    float* lse_s = reinterpret_cast<float*>(dOt + 32 * LDT);  // [32] (log2 domain; +inf marks a dead row)
+    float* dl_s = lse_s + 32;                                  // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h2 = lane >> 5, ql = lane & 31;
+    const int b = blockIdx.z, hd = blockIdx.y, k0 = blockIdx.x * 128;
+    const int kw = k0 + wave * 32, kj = kw + ql;
+    const int off = a.Sk - a.Sq;
+    const int kc = kj < a.Sk ? kj : a.Sk - 1;
+    const bf16_t* kp = a.k + b * a.ks.b + hd * a.ks.h + (int64_t)kc * a.ks.s;
+    const bf16_t* vp = a.v + b * a.vs.b + hd * a.vs.h + (int64_t)kc * a.vs.s;
+    bf16x8_t kf[8], vf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        kf[c] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * c + 8 * h2);
+        vf[c] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * c + 8 * h2);
+    }
+    bool kok = kj < a.Sk;
+    if (a.kvalid) kok = kok && a.kvalid[(int64_t)b * a.Sk + kc] != 0;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    const float bias2 = sl2 * (float)(kj - (a.Sk - 1));
+    const bf16_t* qb = a.q + b * a.qs.b + hd * a.qs.h;
+    const bf16_t* dob = a.dout + b * a.dos.b + hd * a.dos.h;
+    const float* lseb = a.lse + ((int64_t)b * a.H + hd) * a.Sq;
+    const float* dlb = a.delta + ((int64_t)b * a.H + hd) * a.Sq;
+    const int nqt = (a.Sq + 31) >> 5;
+    int qt0 = 0;
+    if (a.causal) {
+        const int imin = k0 - off;
+        qt0 = imin > 0 ? (imin >> 5) : 0;
+    }
+    uint4 qr[2], dr[2];
+    float sr = 0.f, sd = 0.f;
+    auto gload = [&](int qt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + 256 * i, row = ch >> 4, c16 = ch & 15, qrow = qt * 32 + row;
+            if (qrow < a.Sq) {
+                qr[i] = *reinterpret_cast<const uint4*>(qb + (int64_t)qrow * a.qs.s + c16 * 8);
+                dr[i] = *reinterpret_cast<const uint4*>(dob + (int64_t)qrow * a.dos.s + c16 * 8);
+            } else {
+                qr[i] = make_uint4(0, 0, 0, 0);
+                dr[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        if (tid < 32) {
+            const int qrow = qt * 32 + tid;
+            const float l = qrow < a.Sq ? lseb[qrow] : -INFINITY;
+            sr = l == -INFINITY ? INFINITY : l * LOG2E;   // dead row -> exp2(x - inf) = 0
+            sd = qrow < a.Sq ? dlb[qrow] : 0.f;
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + 256 * i, row = ch >> 4, c16 = ch & 15;
+            *reinterpret_cast<uint4*>(Qs + row * LDK + c16 * 8) = qr[i];
+            *reinterpret_cast<uint4*>(Qt + row * LDT + c16 * 8) = qr[i];
+            *reinterpret_cast<uint4*>(dOs + row * LDK + c16 * 8) = dr[i];
+            *reinterpret_cast<uint4*>(dOt + row * LDT + c16 * 8) = dr[i];
+        }
+        if (tid < 32) { lse_s[tid] = sr; dl_s[tid] = sd; }
+    };
+    const int troff = tr_lane_off(lane);
+    f32x16_t dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+    if (qt0 < nqt) gload(qt0);
+    for (int qt = qt0; qt < nqt; ++qt) {
+        __syncthreads();
+        swrite();
+        __syncthreads();
+        if (qt + 1 < nqt) gload(qt + 1);
+        const int i0 = qt * 32;
+        if (a.causal && i0 + 31 + off < kw) continue;  // every query of the tile precedes this wave's keys
+        f32x16_t s = zero16(), dp = zero16();
+        {
+            const bf16_t* qrow = Qs + ql * LDK + 8 * h2;
+            const bf16_t* drow = dOs + ql * LDK + 8 * h2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(qrow + 16 * c), kf[c], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(drow + 16 * c), vf[c], dp, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
+            const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const int i = i0 + 8 * g + 4 * h2 + e;
+                const bool ok = kok && i < a.Sq && (!a.causal || kj <= i + off);
+                const float p = ok ? __builtin_amdgcn_exp2f(s[r] * sc2 + bias2 - lv[e]) : 0.f;
+                s[r] = p;
+                dp[r] = p * (dp[r] - dvv[e]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x8_t pf = pack8(s, 8 * c), dsf = pack8(dp, 8 * c);
+            const bf16_t* tq = Qt + troff + (16 * c) * LDT;
+            const bf16_t* td = dOt + troff + (16 * c) * LDT;
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(td + 32 * db), pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tq + 32 * db), dsf, dk[db], 0, 0, 0);
+            }
+        }
+    }
+    if (kj < a.Sk) {
+        store_dt(a.dk + b * a.dks.b + hd * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, h2);
+        store_dt(a.dv + b * a.dvs.b + hd * a.dvs.h + (int64_t)kj * a.dvs.s, dv, 1.0f, h2);
+    }
+}
+
+int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
+    OTTER_REQUIRE(d && d->q && d->k && d->v && d->o && d->lse, "flash: null pointer");
+    OTTER_REQUIRE(d->head_dim == HD, "flash: head_dim %d (only 128)", d->head_dim);
+    OTTER_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, "flash: empty shape");
+    const otter_flash_view* vs[] = {&d->qv, &d->kv, &d->vv, &d->ov, &d->dov, &d->dqv, &d->dkv, &d->dvv};
+    for (int i = 0; i < (bwd ? 8 : 4); ++i)
+        OTTER_REQUIRE(vs[i]->batch_stride % 8 == 0 && vs[i]->seq_stride % 8 == 0 && vs[i]->head_stride % 8 == 0,
+                      "flash: strides must be multiples of 8 elements");
+    OTTER_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v | (uintptr_t)d->o) & 15) == 0, "flash: 16-byte alignment");
+    memset(&a, 0, sizeof(a));
+    auto st = [](const otter_flash_view& v) { return Str{v.batch_stride, v.seq_stride, v.head_stride}; };
+    a.q = (const bf16_t*)d->q; a.k = (const bf16_t*)d->k; a.v = (const bf16_t*)d->v; a.o = (bf16_t*)d->o;
+    a.qs = st(d->qv); a.ks = st(d->kv); a.vs = st(d->vv); a.os = st(d->ov);
+    a.lse = d->lse; a.slopes = d->alibi_slopes; a.kvalid = d->key_valid;
+    a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Sk = d->Sk; a.causal = d->causal; a.scale = d->scale;
+    if (bwd) {
+        OTTER_REQUIRE(d->dout && d->delta && d->dq && d->dk && d->dv, "flash bwd: null pointer");
+        OTTER_REQUIRE((((uintptr_t)d->dout | (uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) == 0, "flash bwd: 16-byte alignment");
+        a.dout = (const bf16_t*)d->dout; a.dos = st(d->dov); a.delta = d->delta;
+        a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
+        a.dqs = st(d->dqv); a.dks = st(d->dkv); a.dvs = st(d->dvv);
+    }
+    return OTTER_OK;
+}
+
+template <typename K>
+int set_smem(K kern, int bytes) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) OTTER_FAIL(OTTER_ERR_LAUNCH, "flash: hipFuncSetAttribute(%d): %s", bytes, hipGetErrorString(e));
+    return OTTER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
+    FlashArgs a;
+    int rc = fill_args(d, a, false);
+    if (rc) return rc;
+    const int smem = 64 * LDK * 2 + 64 * LDT * 2;
+    static bool once = false;
+    if (!once) { rc = set_smem(flash_fwd_kernel, smem); if (rc) return rc; once = true; }
+    hipLaunchKernelGGL(flash_fwd_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
+    OTTER_CHECK_LAUNCH("flash_fwd");
+    return OTTER_OK;
+}
+
+int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
+    FlashArgs a;
+    int rc = fill_args(d, a, true);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
+    hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, st, a);
+    OTTER_CHECK_LAUNCH("flash_delta");
+    const int smem_kv = (2 * 32 * LDK + 2 * 32 * LDT) * 2 + 64 * 4;
+    const int smem_q = (2 * 64 * LDK + 64 * LDT) * 2;
+    static bool once = false;
+    if (!once) {
+        rc = set_smem(flash_bwd_dkv_kernel, smem_kv); if (rc) return rc;
+        rc = set_smem(flash_bwd_dq_kernel, smem_q); if (rc) return rc;
+        once = true;
+    }
+    hipLaunchKernelGGL(flash_bwd_dkv_kernel, dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), smem_kv, st, a);
+    OTTER_CHECK_LAUNCH("flash_bwd_dkv");
+    hipLaunchKernelGGL(flash_bwd_dq_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), smem_q, st, a);
+    OTTER_CHECK_LAUNCH("flash_bwd_dq");
+    return OTTER_OK;
+}
+
+}  // extern "C"

@@ -253,6 +253,39 @@ class AttnCoreFn(torch.autograd.Function):
         return dq, dkv, None, None, None, None
 
 
+class FlashSelfAttentionFn(torch.autograd.Function):
+    """Causal / ALiBi / key-padding self-attention of the frozen decoder host on the fused Wqkv output
+    (mpt/attention.py:22-84; bias :447-464): qkv [B,S,3*H*128] bf16 -> ctx [B,S,H*128] bf16.  q, k, v and the three
+    gradient slices are addressed in place inside qkv / dqkv (no chunk or cat copies)."""
+
+    @staticmethod
+    def forward(ctx, qkv, n_heads, slopes, key_valid, scale, causal):
+        B, S, D3 = qkv.shape
+        qkv = qkv.contiguous()
+        v5 = qkv.view(B, S, 3, n_heads, 128)
+        o, lse = ops.flash_attn_fwd(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], slopes, key_valid, scale, causal)
+        ctx.save_for_backward(qkv, o, lse, slopes, key_valid)
+        ctx.cfg = (n_heads, scale, causal)
+        return o.view(B, S, n_heads * 128)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, o, lse, slopes, key_valid = ctx.saved_tensors
+        n_heads, scale, causal = ctx.cfg
+        B, S, _ = qkv.shape
+        v5 = qkv.view(B, S, 3, n_heads, 128)
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(B, S, 3, n_heads, 128)
+        dout = dout.to(torch.bfloat16).contiguous().view(B, S, n_heads, 128)
+        ops.flash_attn_bwd(v5[:, :, 0], v5[:, :, 1], v5[:, :, 2], o, lse, dout, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2],
+                           slopes, key_valid, scale, causal)
+        return dqkv, None, None, None, None, None
+
+
+def flash_self_attention(qkv, n_heads, slopes, key_valid, scale, causal=True):
+    return FlashSelfAttentionFn.apply(qkv, n_heads, slopes, key_valid, scale, causal)
+
+
 def masked_cross_attention(x, media, tt, mask_mode, heads, eps, norm_w, norm_b, Wq, Wkv, Wo):
     """OtterMaskedCrossAttention.forward (modeling_otter.py:262-340) used stand-alone: returns to_out(attn) in the compute
     dtype (bf16 under autocast, like the reference)."""

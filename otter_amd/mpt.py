@@ -11,6 +11,7 @@ libotter_hip.so.  What this file must get exactly right is the contract the hot 
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -110,10 +111,20 @@ class MultiheadAttention(nn.Module):
         self.Wqkv = nn.Linear(d_model, 3 * d_model, bias=bias)
         self.out_proj = nn.Linear(d_model, d_model, bias=bias)
 
-    def forward(self, x, past_key_value=None, attn_bias=None, is_causal=True):
+    def forward(self, x, past_key_value=None, attn_bias=None, is_causal=True, flash=None):
         B, S, D = x.shape
         H, d = self.n_heads, D // self.n_heads
-        q, k, v = self.Wqkv(x).chunk(3, dim=2)
+        qkv = self.Wqkv(x)
+        if flash is not None:
+            # HIP flash attention on the fused projection output (otter_amd/csrc/flash.hip): ALiBi, causal and key-padding
+            # masks are evaluated inside the kernel, q/k/v and their gradients are slices of one buffer
+            slopes, key_valid = flash
+            ctx = OF.flash_self_attention(qkv, H, slopes, key_valid, self.softmax_scale, is_causal)
+            if past_key_value is not None:
+                kv5 = qkv.view(B, S, 3, H, d)
+                past_key_value = (kv5[:, :, 1].permute(0, 2, 3, 1), kv5[:, :, 2].transpose(1, 2))  # k [B,H,d,S], v [B,H,S,d]
+            return self.out_proj(ctx), past_key_value
+        q, k, v = qkv.chunk(3, dim=2)
         q = q.view(B, S, H, d).transpose(1, 2)  # [B,H,S,d]
         k = k.view(B, S, H, d).transpose(1, 2)
         v = v.view(B, S, H, d).transpose(1, 2)
@@ -141,7 +152,7 @@ class MPTBlock(nn.Module):
         self.ffn = MPTMLP(config.d_model, config.expansion_ratio, bias)
 
     def forward(self, x, past_key_value=None, attn_bias=None, attention_mask=None, is_causal=True, deferred=None,
-                defer_out=False):
+                defer_out=False, flash=None):
         """`deferred` / `defer_out` (otter_amd extension, used by MPTModel.forward): the FFN output of a block is handed to
         the NEXT block un-added, where the residual add is fused into that block's norm_1 pass (one trip over the fp32
         residual stream instead of two).  With the defaults this is exactly mpt/blocks.py:68-88."""
@@ -149,7 +160,7 @@ class MPTBlock(nn.Module):
             x, a = self.norm_1.add_forward(x, deferred)   # x = x + ffn_out(prev) ; a = norm_1(x)
         else:
             a = self.norm_1(x)
-        b, past_key_value = self.attn(a, past_key_value=past_key_value, attn_bias=attn_bias, is_causal=is_causal)
+        b, past_key_value = self.attn(a, past_key_value=past_key_value, attn_bias=attn_bias, is_causal=is_causal, flash=flash)
         x, m = self.norm_2.add_forward(x, b)              # x = x + b ; m = norm_2(x)
         n = self.ffn(m)
         if defer_out:
@@ -204,6 +215,25 @@ class MPTModel(MPTPreTrainedModel):
                 bias = bias.masked_fill(~am.view(-1, 1, 1, s_k), torch.finfo(torch.float32).min)
         return bias
 
+    def _flash_spec(self, x, s_past: int, attention_mask):
+        """(alibi slopes [H] fp32, key_valid [B,S] uint8 or None) when the HIP flash-attention kernel covers this call:
+        bf16 compute on the GPU, head_dim 128, no KV cache to prepend, no left padding (a fully masked query row comes
+        out as the uniform average in the reference and as 0 in the kernel).  Otherwise None -> additive-mask SDPA path."""
+        if not x.is_cuda or s_past != 0 or not self.is_causal or OF.compute_dtype_for(x) != torch.bfloat16:
+            return None
+        if self.config.d_model // self.config.n_heads != 128 or os.environ.get("OTTER_NO_FLASH") == "1":
+            return None
+        key_valid = None
+        if attention_mask is not None:
+            am = attention_mask.bool()
+            if not bool(am.all()):
+                if not bool(am[:, 0].all()):
+                    return None
+                key_valid = am.to(torch.uint8).contiguous()
+        if self._slopes is None or self._slopes.device != x.device:
+            self._slopes = alibi_slopes(self.config.n_heads, self.alibi_bias_max).to(x.device)
+        return self._slopes.float().contiguous(), key_valid
+
     def forward(self, input_ids, past_key_values=None, attention_mask=None, use_cache=None, return_dict=True, **unused):
         use_cache = use_cache if use_cache is not None else self.config.use_cache
         if attention_mask is not None and self.training and int(attention_mask[:, 0].sum()) != attention_mask.shape[0]:
@@ -215,13 +245,15 @@ class MPTModel(MPTPreTrainedModel):
         s_past = 0
         if past_key_values is not None and len(past_key_values) and len(past_key_values[0]) != 0:
             s_past = past_key_values[0][0].size(3)
-        # one additive mask per forward, shared by every block: ALiBi (+ padding) and, for S > 1, the causal triangle
         s_k = S + s_past
-        attn_bias = self._attn_bias(s_k, x.device, attention_mask)
-        if self.is_causal and S != 1:
-            causal = torch.ones(S, s_k, dtype=torch.bool, device=x.device).tril(diagonal=s_k - S)
-            attn_bias = attn_bias.expand(-1, -1, S, -1).masked_fill(~causal, torch.finfo(torch.float32).min)
-        attn_bias = attn_bias.to(OF.compute_dtype_for(x))
+        flash, attn_bias = self._flash_spec(x, s_past, attention_mask), None
+        if flash is None:
+            # one additive mask per forward, shared by every block: ALiBi (+ padding) and, for S > 1, the causal triangle
+            attn_bias = self._attn_bias(s_k, x.device, attention_mask)
+            if self.is_causal and S != 1:
+                causal = torch.ones(S, s_k, dtype=torch.bool, device=x.device).tril(diagonal=s_k - S)
+                attn_bias = attn_bias.expand(-1, -1, S, -1).masked_fill(~causal, torch.finfo(torch.float32).min)
+            attn_bias = attn_bias.to(OF.compute_dtype_for(x))
         if use_cache and past_key_values is None:
             past_key_values = [() for _ in range(self.config.n_layers)]
         # Each block hands its FFN output over un-added (`delta`); the add is fused into the next LayerNorm pass.  A wrapper
@@ -234,7 +266,7 @@ class MPTModel(MPTPreTrainedModel):
                 x = x + delta
                 delta = None
             out = block(x, past_key_value=pkv, attn_bias=attn_bias, attention_mask=None, is_causal=self.is_causal,
-                        deferred=delta, defer_out=True)
+                        deferred=delta, defer_out=True, flash=flash)
             x, pkv = out[0], out[2]
             delta = out[3] if len(out) > 3 else None
             if past_key_values is not None:

@@ -268,6 +268,55 @@ def attn_bwd(q, k, v, o, do, lse, H, tt, n_per_media, mask_mode, scale, dkv_out=
 # ----------------------------------------------------------------------------------------------------------------------
 
 
+def _flash_view(t: torch.Tensor) -> K.FlashView:
+    """t: a [B, S, H, 128] bf16 view with unit stride along the head dim."""
+    if t.dim() != 4 or t.shape[3] != 128 or t.stride(3) != 1 or t.dtype != torch.bfloat16:
+        raise K.OtterHipError(f"flash attention wants [B,S,H,128] bf16 views (got {tuple(t.shape)}, {t.dtype}, strides {t.stride()})")
+    return K.FlashView(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _flash_desc(q, k, v, o, lse, slopes, key_valid, scale, causal) -> K.FlashDesc:
+    K.require_cuda(q, k, v, o, lse, slopes, key_valid)
+    B, Sq, H, _ = q.shape
+    Sk = k.shape[1]
+    if key_valid is not None and (key_valid.dtype != torch.uint8 or not key_valid.is_contiguous() or key_valid.shape != (B, Sk)):
+        raise K.OtterHipError("flash attention: key_valid must be a contiguous uint8 [B, Sk] tensor")
+    if slopes is not None and (slopes.dtype != torch.float32 or not slopes.is_contiguous() or slopes.numel() != H):
+        raise K.OtterHipError("flash attention: alibi slopes must be a contiguous fp32 [H] tensor")
+    d = K.FlashDesc()
+    d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    d.qv, d.kv, d.vv, d.ov = _flash_view(q), _flash_view(k), _flash_view(v), _flash_view(o)
+    d.lse = lse.data_ptr()
+    d.alibi_slopes = K.ptr(slopes)
+    d.key_valid = K.ptr(key_valid)
+    d.B, d.H, d.Sq, d.Sk, d.head_dim, d.causal = B, H, Sq, Sk, 128, int(bool(causal))
+    d.scale = float(scale)
+    return d
+
+
+def flash_attn_fwd(q, k, v, slopes, key_valid, scale, causal=True):
+    """Decoder-host attention (mpt/attention.py:22-84 + ALiBi :447-464) on [B,S,H,128] bf16 views.  Returns
+    (o [B,Sq,H,128] contiguous, lse [B,H,Sq] fp32)."""
+    B, Sq, H, _ = q.shape
+    o = torch.empty((B, Sq, H, 128), dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    d = _flash_desc(q, k, v, o, lse, slopes, key_valid, scale, causal)
+    K.check(K.lib().otter_flash_attn_fwd(C.byref(d), K.stream()), "flash_attn_fwd")
+    return o, lse
+
+
+def flash_attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, slopes, key_valid, scale, causal=True):
+    """Writes dq / dk / dv (caller-provided [B,S,H,128] views, e.g. the three slices of one dqkv buffer)."""
+    K.require_cuda(dout, dq, dk, dv)
+    d = _flash_desc(q, k, v, o, lse, slopes, key_valid, scale, causal)
+    delta = torch.empty_like(lse)
+    d.dout, d.dov = dout.data_ptr(), _flash_view(dout)
+    d.delta = delta.data_ptr()
+    d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    d.dqv, d.dkv, d.dvv = _flash_view(dq), _flash_view(dk), _flash_view(dv)
+    K.check(K.lib().otter_flash_attn_bwd(C.byref(d), K.stream()), "flash_attn_bwd")
+
+
 def rope(x, cos, sin, rot_dim=None, inverse=False, out=None):
     """x [B,S,H,d] contiguous, cos/sin fp32 [S,rot]."""
     K.require_cuda(x, cos, sin)
