@@ -44,6 +44,19 @@ def build_diag(mask: int, verbose: bool = True) -> str:
     return out
 
 
+def build_flash_timing(verbose: bool = True) -> str:
+    """Diagnostics build with the in-kernel timeline of the flash forward (-DOTTER_FLASH_TIMING) ->
+    lib/libotter_hip_flashtiming.so; only tools/flash_timeline.py loads it."""
+    build(verbose=verbose)
+    cc = hipcc()
+    obj = os.path.join(LIBDIR, "flash_timing.o")
+    out = os.path.join(LIBDIR, "libotter_hip_flashtiming.so")
+    subprocess.check_call([cc, *FLAGS, "-DOTTER_FLASH_TIMING", "-c", os.path.join(CSRC, "flash.hip"), "-o", obj])
+    others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "flash.hip"]
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "otter_hip.h")]
@@ -73,7 +86,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    if "--diag" in sys.argv:
+    if "--flash-timing" in sys.argv:
+        print(build_flash_timing())
+    elif "--diag" in sys.argv:
         print(build_diag(int(sys.argv[sys.argv.index("--diag") + 1])))
     else:
         print(build(force="--force" in sys.argv))

@@ -50,6 +50,20 @@ struct FlashArgs {
     bf16_t* dq; bf16_t* dk; bf16_t* dv; Str dqs, dks, dvs;
 };
 
+// In-kernel timeline of workgroup (3,0,0) / wave 0 of the forward (diagnostics build only: -DOTTER_FLASH_TIMING)
+#ifdef OTTER_FLASH_TIMING
+__device__ unsigned long long* g_flash_stamps = nullptr;
+#define STAMP(slot)                                                                                       \
+    do {                                                                                                  \
+        unsigned long long t_;                                                                            \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if (g_flash_stamps && blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (slot) < 64) \
+            g_flash_stamps[slot] = t_;                                                                    \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ f32x16_t zero16() {
     f32x16_t z;
 #pragma unroll
@@ -143,11 +157,15 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
     f32x16_t o[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = zero16();
+    STAMP(0);
     if (nkt > 0) gload(0);
+    STAMP(1);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
+        STAMP(2 + 6 * kt);
         swrite();
         __syncthreads();
+        STAMP(3 + 6 * kt);
         if (kt + 1 < nkt) gload(kt + 1);
         const int k0 = kt * 64;
         if (a.causal && k0 > q0 + wave * 32 + 31 + off) continue;  // whole tile above this wave's diagonal
@@ -182,7 +200,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
                 s[kbk][r] = x;
                 mx = fmaxf(mx, x);
             }
+        STAMP(4 + 6 * kt);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        STAMP(5 + 6 * kt);
         const float mnew = fmaxf(m, mx);
         const float muse = mnew == -INFINITY ? 0.f : mnew;
         const float alpha = __builtin_amdgcn_exp2f(m - muse);
@@ -200,6 +220,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
         for (int db = 0; db < 4; ++db)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        STAMP(6 + 6 * kt);
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
@@ -209,13 +230,16 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
 #pragma unroll
                 for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tp + 32 * db), pf, o[db], 0, 0, 0);
             }
+        STAMP(7 + 6 * kt);
     }
+    STAMP(60);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
     if (qi < a.Sq) {
         store_dt(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s, o, inv, h2);
         if (h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
     }
+    STAMP(61);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -544,5 +568,12 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
     OTTER_CHECK_LAUNCH("flash_bwd_dq");
     return OTTER_OK;
 }
+
+#ifdef OTTER_FLASH_TIMING
+int otter_flash_set_stamps(void* dev_ptr) {  // diagnostics builds only; not part of include/otter_hip.h
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_flash_stamps), &dev_ptr, sizeof(void*));
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

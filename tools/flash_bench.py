@@ -9,6 +9,8 @@ from otter_amd.mpt import alibi_slopes
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+CAUSAL = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
+SDPA = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
 H = 32
 
 def bench(fn, iters=20):
@@ -24,11 +26,17 @@ dout = torch.randn(B, S, H, 128, device="cuda").to(torch.bfloat16)
 sl = alibi_slopes(H, 8).float().cuda()
 scale = 1 / math.sqrt(128)
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-o, lse = ops.flash_attn_fwd(q, k, v, sl, None, scale, True)
+o, lse = ops.flash_attn_fwd(q, k, v, sl, None, scale, CAUSAL)
 dqkv = torch.empty_like(qkv)
-res = {"B": B, "S": S, "H": H}
-res["hip_fwd_us"] = bench(lambda: ops.flash_attn_fwd(q, k, v, sl, None, scale, True))
-res["hip_bwd_us"] = bench(lambda: ops.flash_attn_bwd(q, k, v, o, lse, dout, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], sl, None, scale, True))
+res = {"B": B, "S": S, "H": H, "causal": CAUSAL}
+res["hip_fwd_us"] = bench(lambda: ops.flash_attn_fwd(q, k, v, sl, None, scale, CAUSAL))
+res["hip_bwd_us"] = bench(lambda: ops.flash_attn_bwd(q, k, v, o, lse, dout, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], sl, None, scale, CAUSAL))
+fl = 4 * B * H * S * S * 128 * (0.5 if CAUSAL else 1.0)
+res["hip_fwd_TF"] = fl / res["hip_fwd_us"] / 1e6
+res["hip_bwd_TF"] = 2.5 * fl / res["hip_bwd_us"] / 1e6
+if not SDPA:
+    print(json.dumps({k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in res.items()}))
+    sys.exit(0)
 # the path it replaces: chunked views -> SDPA with an additive [1,H,S,S] bf16 mask
 bias = (torch.arange(1 - S, 1, dtype=torch.float32, device="cuda").view(1, 1, 1, S) * sl.view(1, H, 1, 1))
 causal = torch.ones(S, S, dtype=torch.bool, device="cuda").tril()
@@ -41,7 +49,4 @@ out = sdpa_f(); g = dout.transpose(1, 2)
 def sdpa_b():
     out.backward(g, retain_graph=True)
 res["sdpa_bwd_us"] = bench(sdpa_b)
-fl = 4 * B * H * S * S * 128 * 0.5
-res["hip_fwd_TF"] = fl / res["hip_fwd_us"] / 1e6
-res["hip_bwd_TF"] = 2.5 * fl / res["hip_bwd_us"] / 1e6
 print(json.dumps({k_: (round(v_, 1) if isinstance(v_, float) else v_) for k_, v_ in res.items()}))
