@@ -183,8 +183,8 @@ int otter_attn_bwd(const void* q, int64_t q_stride, const void* k, const void* v
  * out = softmax(scale * q k^T + bias + masks) v without materialising the scores; the bias is evaluated in fp32 in
  * the kernel.  q/k/v/o (and the gradients) are [B, S, H, 128] views given by element strides, so the three slices
  * of a fused Wqkv output and of its gradient buffer are addressed in place (no chunk/cat copies).
- * lse [B,H,Sq] fp32 (natural log) is written by the forward and read by the backward; delta [B,H,Sq] fp32 is
- * backward workspace.  A query row with no visible key yields 0 (lse = -inf) and zero gradients; the reference's
+ * lse [B,H,Sq] fp32 (natural log) is written by the forward and read by the backward; delta is backward workspace of
+ * 2*B*H*Sq floats (row dot products, then a log2-domain copy of lse).  A query row with no visible key yields 0 (lse = -inf) and zero gradients; the reference's
  * masked_fill(finfo.min) would yield the uniform average there -- such rows only exist for left-padded prompts,
  * which the host routes to its SDPA path.
  * ------------------------------------------------------------------------------------------------------- */
@@ -207,6 +207,8 @@ typedef struct otter_flash_desc {
 } otter_flash_desc;
 
 int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream);
+/* tuning / A-B hook: 0 = default kernels, 1 = register-staged tiles (v1), 2 = LDS-DMA tiles (v2) */
+int otter_flash_set_variant(int variant);
 int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------

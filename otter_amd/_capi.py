@@ -89,6 +89,7 @@ SIGNATURES = {
     "otter_add_rows": (_int, [_vp, _vp, RowMap, _i64, _i64, _int, _vp]),
     "otter_flash_attn_fwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_flash_attn_bwd": (_int, [C.POINTER(FlashDesc), _vp]),
+    "otter_flash_set_variant": (_int, [_int]),
     "otter_prof_arm_gemm": (_int, [_i64, _i64, _i64, _int]),
     "otter_prof_disarm": (_int, []),
     "otter_prof_collect": (_int, [C.POINTER(_int), C.POINTER(C.c_double)]),

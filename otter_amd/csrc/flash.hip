@@ -243,6 +243,170 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// forward, version 2: same math and orientation; K/V tiles arrive by LDS-DMA (buffer_load_dwordx4 ... lds: no staging
+// registers, no ds_write pass, rows past Sk are zero-filled by the buffer range check), double-buffered with ONE raw
+// barrier per tile, unpadded 256-B rows with XOR swizzles applied on the DMA source offsets:
+//   K (row fragments, ds_read_b128): 16-B slot ^= row & 15        -> the 16 rows of a lane group hit 16 distinct slots
+//   V (ds_read_b64_tr_b16):          64-B block ^= row & 3        -> the 4 rows of a transpose read hit 4 distinct blocks
+// 64 KB of LDS and <= 256 registers per lane: two workgroups per CU, so one wave's softmax VALU / LDS latency runs under
+// the co-resident wave's MFMAs.  Less VALU: tiles entirely below the diagonal skip the mask arithmetic, and the
+// accumulator is only rescaled when some row's running maximum grew by more than 2^8 (stale maxima are exact: P <= 256).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flash_dma_tile(__amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv, char* kdst, char* vdst,
+                                               const uint32_t (&vk)[4], const uint32_t (&vv)[4], int wave, uint32_t ksoff,
+                                               uint32_t vsoff) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kdst + (wave * 4 + i) * 1024), 16,
+                                                 (int)vk[i], (int)ksoff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vdst + (wave * 4 + i) * 1024), 16,
+                                                 (int)vv[i], (int)vsoff, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
+    const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128;
+    const int qi = q0 + wave * 32 + ql;
+    const int off = a.Sk - a.Sq;
+    const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)(qi < a.Sq ? qi : a.Sq - 1) * a.qs.s;
+    bf16x8_t qf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2);
+    const bf16_t* kb = a.k + b * a.ks.b + hd * a.ks.h;
+    const bf16_t* vb = a.v + b * a.vs.b + hd * a.vs.h;
+    const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    int nkt = (a.Sk + 63) >> 6;
+    if (a.causal) {
+        const int qmax = (q0 + 127 < a.Sq ? q0 + 127 : a.Sq - 1) + off;
+        const int lim = qmax < 0 ? 0 : (qmax >> 6) + 1;
+        nkt = nkt < lim ? nkt : lim;
+    }
+    const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, (int)((uint32_t)(a.Sk - 1) * krow + 256u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, (int)((uint32_t)(a.Sk - 1) * vrow + 256u), 0x00020000);
+    uint32_t vk[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = 4 * (wave * 4 + i) + (lane >> 4), p = lane & 15;
+        vk[i] = (uint32_t)rl * krow + (uint32_t)((p ^ (rl & 15)) << 4);
+        vv[i] = (uint32_t)rl * vrow + (uint32_t)(((((p >> 2) ^ (rl & 3)) << 2) | (p & 3)) << 4);
+    }
+    // read side: K row fragment of row 32 kbk + ql, logical slot 2c + h2 -> byte ((32c) ^ (y << 4)) with y = h2 ^ (ql & 15);
+    // V transpose read: lane i of a 16-lane group supplies row 4h + (i>>2) (+ key base, + 8), d block db at 64-B block
+    // db ^ (i>>2): one per-lane base, the d block as an XOR on bits 6-7, everything else as immediates
+    const int kfo = ql * 256 + ((h2 ^ (ql & 15)) << 4);
+    const int gi = lane & 15, gg = lane >> 4;
+    const int vto = (4 * (gg >> 1) + (gi >> 2)) * 256 + ((gi >> 2) << 6) + 32 * (gg & 1) + 8 * (gi & 3);
+    float m = -INFINITY, lsum = 0.f;
+    f32x16_t o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = zero16();
+    if (nkt > 0) flash_dma_tile(rk, rv, smem, smem + 32768, vk, vv, wave, 0u, 0u);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave; every wave is done with tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt)
+            flash_dma_tile(rk, rv, smem + (cur ^ 1) * 16384, smem + 32768 + (cur ^ 1) * 16384, vk, vv, wave, (uint32_t)(kt + 1) * 64u * krow,
+                           (uint32_t)(kt + 1) * 64u * vrow);
+        const int k0 = kt * 64;
+        const int wq0 = q0 + wave * 32 + off;  // first query of the wave, in key coordinates
+        if (a.causal && k0 > wq0 + 31) continue;  // whole tile above this wave's diagonal
+        const char* Kc = smem + cur * 16384;
+        const char* Vc = smem + 32768 + cur * 16384;
+        f32x16_t s[2];
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            s[kbk] = zero16();
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    *reinterpret_cast<const bf16x8_t*>(Kc + kbk * 8192 + (kfo ^ (32 * c))), qf[c], s[kbk], 0, 0, 0);
+        }
+        const float base = sl2 * (float)(k0 + 4 * h2 - (a.Sk - 1));
+        float mx = -INFINITY;
+        const bool interior = kv == nullptr && k0 + 63 < a.Sk && (!a.causal || k0 + 63 <= wq0);
+        if (interior) {
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                    const float x = fmaf(s[kbk][r], sc2, fmaf(sl2, (float)cidx, base));
+                    s[kbk][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+        } else {
+            const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
+            const int limh = (a.causal && rel < kend ? rel : kend) - 4 * h2;
+            unsigned long long vmh = ~0ull;
+            if (kv) {
+                const int jj = k0 + lane;
+                vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
+            }
+#pragma unroll
+            for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                    float x = fmaf(s[kbk][r], sc2, fmaf(sl2, (float)cidx, base));
+                    const bool ok = cidx <= limh && ((vmh >> cidx) & 1ull);
+                    x = ok ? x : -INFINITY;
+                    s[kbk][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // lazy rescale: only when some row's maximum grew by more than 8 (log2 units) -- wave-uniform decision
+        if (__ballot(mx > m + 8.0f) != 0ull) {
+            const float mnew = fmaxf(m, mx);
+            const float muse = mnew == -INFINITY ? 0.f : mnew;
+            const float alpha = __builtin_amdgcn_exp2f(m - muse);
+            m = mnew;
+            lsum *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float muse = m == -INFINITY ? 0.f : m;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kbk][r] - muse);
+                s[kbk][r] = p;
+                lsum += p;
+            }
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8_t pf = pack8(s[kbk], 8 * c);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    const char* tp = Vc + (vto ^ (db << 6)) + (32 * kbk + 16 * c) * 256;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)tp);
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tp + 2048));
+                    const s16x8_t vfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vfr), pf, o[db], 0, 0, 0);
+                }
+            }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    if (qi < a.Sq) {
+        store_dt(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s, o, inv, h2);
+        if (h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // delta[b,h,q] = sum_d dO . O   (16 lanes per row)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
@@ -262,7 +426,11 @@ __global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (row < nrows && c == 0) a.delta[row] = acc;
+    if (row < nrows && c == 0) {
+        a.delta[row] = acc;
+        const float l = a.lse[row];
+        a.delta[nrows + row] = l == -INFINITY ? INFINITY : l * LOG2E;  // exp2(x - inf) = 0: a dead row contributes nothing
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -498,6 +666,248 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// backward, version 2 (LDS-DMA tiles, one raw barrier per tile, double buffering; see flash_fwd2_kernel).
+// A tile that is read BOTH as row fragments (ds_read_b128) and through the transpose read uses the swizzle
+//   16-B slot ^= pi(row & 15),  pi(x) = ((x & 3) << 2) | (x >> 2)
+// pi is a bijection on 0..15 (16 rows of a ds_read_b128 lane group -> 16 distinct slots) whose upper two bits are
+// row & 3 (the 4 rows of a transpose read -> 4 distinct 64-B blocks): one LDS copy is conflict-free for both.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pi16(int x) { return ((x & 3) << 2) | ((x >> 2) & 3); }
+
+// per-lane byte offsets of the two transpose reads (rows +0 and +8 of a 16-row k chunk) inside a pi-swizzled tile
+__device__ __forceinline__ void tr_pi_offsets(int lane, int& o1, int& o2) {
+    const int gi = lane & 15, gg = lane >> 4, j = gi >> 2, h = gg >> 1;
+    const int lo = 2 * (gg & 1) + ((gi & 3) >> 1);
+    o1 = (4 * h + j) * 256 + (j << 6) + 16 * (lo ^ h) + 8 * (gi & 1);
+    o2 = (4 * h + j + 8) * 256 + (j << 6) + 16 * (lo ^ h ^ 2) + 8 * (gi & 1);
+}
+__device__ __forceinline__ bf16x8_t tr_pi_frag(const char* tile, int o1, int o2, int db, int rowbase) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + (o1 ^ (db << 6)) + rowbase * 256));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + (o2 ^ (db << 6)) + rowbase * 256));
+    const s16x8_t r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
+    const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 128;
+    const int qi = q0 + wave * 32 + ql;
+    const int qc = qi < a.Sq ? qi : a.Sq - 1;
+    const int off = a.Sk - a.Sq;
+    const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)qc * a.qs.s;
+    const bf16_t* dop = a.dout + b * a.dos.b + hd * a.dos.h + (int64_t)qc * a.dos.s;
+    bf16x8_t qf[8], dof[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2);
+        dof[c] = *reinterpret_cast<const bf16x8_t*>(dop + 16 * c + 8 * h2);
+    }
+    const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
+    const int64_t srow = ((int64_t)b * a.H + hd) * a.Sq + qc;
+    const float lse2 = qi < a.Sq ? a.delta[nrows + srow] : INFINITY, dl = a.delta[srow];
+    const bf16_t* kb = a.k + b * a.ks.b + hd * a.ks.h;
+    const bf16_t* vb = a.v + b * a.vs.b + hd * a.vs.h;
+    const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    int nkt = (a.Sk + 63) >> 6;
+    if (a.causal) {
+        const int qmax = (q0 + 127 < a.Sq ? q0 + 127 : a.Sq - 1) + off;
+        const int lim = qmax < 0 ? 0 : (qmax >> 6) + 1;
+        nkt = nkt < lim ? nkt : lim;
+    }
+    const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, (int)((uint32_t)(a.Sk - 1) * krow + 256u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, (int)((uint32_t)(a.Sk - 1) * vrow + 256u), 0x00020000);
+    uint32_t vk[4], vv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = 4 * (wave * 4 + i) + (lane >> 4), p = lane & 15;
+        vk[i] = (uint32_t)rl * krow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
+        vv[i] = (uint32_t)rl * vrow + (uint32_t)((p ^ (rl & 15)) << 4);
+    }
+    const int kfo = ql * 256 + ((h2 ^ pi16(ql & 15)) << 4);
+    const int vfo = ql * 256 + ((h2 ^ (ql & 15)) << 4);
+    int to1, to2;
+    tr_pi_offsets(lane, to1, to2);
+    f32x16_t dq[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dq[db] = zero16();
+    if (nkt > 0) flash_dma_tile(rk, rv, smem, smem + 32768, vk, vv, wave, 0u, 0u);
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt)
+            flash_dma_tile(rk, rv, smem + (cur ^ 1) * 16384, smem + 32768 + (cur ^ 1) * 16384, vk, vv, wave, (uint32_t)(kt + 1) * 64u * krow,
+                           (uint32_t)(kt + 1) * 64u * vrow);
+        const int k0 = kt * 64;
+        const int wq0 = q0 + wave * 32 + off;
+        if (a.causal && k0 > wq0 + 31) continue;
+        const char* Kc = smem + cur * 16384;
+        const char* Vc = smem + 32768 + cur * 16384;
+        const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
+        const int limh = (a.causal && rel < kend ? rel : kend) - 4 * h2;
+        const float base = sl2 * (float)(k0 + 4 * h2 - (a.Sk - 1)) - lse2;
+        const bool interior = kv == nullptr && k0 + 63 < a.Sk && (!a.causal || k0 + 63 <= wq0);
+        unsigned long long vmh = ~0ull;
+        if (kv) {
+            const int jj = k0 + lane;
+            vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
+        }
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+            f32x16_t s = zero16(), dp = zero16();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Kc + kbk * 8192 + (kfo ^ (32 * c))), qf[c], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Vc + kbk * 8192 + (vfo ^ (32 * c))), dof[c], dp, 0, 0, 0);
+            }
+            if (interior) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, fmaf(sl2, (float)cidx, base)));
+                    s[r] = p * (dp[r] - dl);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                    const bool ok = cidx <= limh && ((vmh >> cidx) & 1ull);
+                    const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc2, fmaf(sl2, (float)cidx, base))) : 0.f;
+                    s[r] = p * (dp[r] - dl);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8_t dsf = pack8(s, 8 * c);
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Kc, to1, to2, db, 32 * kbk + 16 * c), dsf, dq[db], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < a.Sq) store_dt(a.dq + b * a.dqs.b + hd * a.dqs.h + (int64_t)qi * a.dqs.s, dq, a.scale, h2);
+}
+
+__global__ __launch_bounds__(256) void flash_bwd_dkv2_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // Q0 | Q1 | dO0 | dO1 (8 KB each) | lse2[2][64] | delta[2][64]
+    const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, hd = blockIdx.y, k0 = blockIdx.x * 128;
+    const int kw = k0 + wave * 32, kj = kw + ql;
+    const int off = a.Sk - a.Sq;
+    const int kc = kj < a.Sk ? kj : a.Sk - 1;
+    const bf16_t* kp = a.k + b * a.ks.b + hd * a.ks.h + (int64_t)kc * a.ks.s;
+    const bf16_t* vp = a.v + b * a.vs.b + hd * a.vs.h + (int64_t)kc * a.vs.s;
+    bf16x8_t kf[8], vf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        kf[c] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * c + 8 * h2);
+        vf[c] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * c + 8 * h2);
+    }
+    bool kok = kj < a.Sk;
+    if (a.kvalid) kok = kok && a.kvalid[(int64_t)b * a.Sk + kc] != 0;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    const float bias2 = sl2 * (float)(kj - (a.Sk - 1));
+    const bf16_t* qb = a.q + b * a.qs.b + hd * a.qs.h;
+    const bf16_t* dob = a.dout + b * a.dos.b + hd * a.dos.h;
+    const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
+    const float* dlb = a.delta + ((int64_t)b * a.H + hd) * a.Sq;
+    const float* lsb = dlb + nrows;
+    const int nqt = (a.Sq + 31) >> 5;
+    int qt0 = 0;
+    if (a.causal) {
+        const int imin = k0 - off;
+        qt0 = imin > 0 ? (imin >> 5) : 0;
+    }
+    const uint32_t qrow = (uint32_t)(a.qs.s * 2), dorow = (uint32_t)(a.dos.s * 2);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (int)((uint32_t)(a.Sq - 1) * qrow + 256u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dob), 0, (int)((uint32_t)(a.Sq - 1) * dorow + 256u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rls = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lsb), 0, a.Sq * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dlb), 0, a.Sq * 4, 0x00020000);
+    uint32_t vq[2], vd[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rl = 4 * (wave * 2 + i) + (lane >> 4), p = lane & 15;
+        vq[i] = (uint32_t)rl * qrow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
+        vd[i] = (uint32_t)rl * dorow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
+    }
+    char* const stat = smem + 32768;
+    auto issue = [&](int qt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(smem + buf * 8192 + (wave * 2 + i) * 1024), 16,
+                                                     (int)vq[i], (int)((uint32_t)qt * 32u * qrow), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(smem + 16384 + buf * 8192 + (wave * 2 + i) * 1024), 16,
+                                                     (int)vd[i], (int)((uint32_t)qt * 32u * dorow), 0, 0);
+        }
+        if (wave == 0) {  // 64 floats each (the upper 32 belong to the next tile; rows past Sq read as 0 and are masked)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rls, (__attribute__((address_space(3))) void*)(stat + buf * 256), 4, lane * 4, qt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, (__attribute__((address_space(3))) void*)(stat + 512 + buf * 256), 4, lane * 4, qt * 128, 0, 0);
+        }
+    };
+    const int qfo = ql * 256 + ((h2 ^ pi16(ql & 15)) << 4);
+    int to1, to2;
+    tr_pi_offsets(lane, to1, to2);
+    f32x16_t dk[4], dv[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+    if (qt0 < nqt) issue(qt0, 0);
+    for (int qt = qt0; qt < nqt; ++qt) {
+        const int cur = (qt - qt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (qt + 1 < nqt) issue(qt + 1, cur ^ 1);
+        const int i0 = qt * 32;
+        if (a.causal && i0 + 31 + off < kw) continue;  // every query of the tile precedes this wave's keys
+        const char* Qc = smem + cur * 8192;
+        const char* Dc = smem + 16384 + cur * 8192;
+        const float* lse_s = reinterpret_cast<const float*>(stat + cur * 256);
+        const float* dl_s = reinterpret_cast<const float*>(stat + 512 + cur * 256);
+        f32x16_t s = zero16(), dp = zero16();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Qc + (qfo ^ (32 * c))), kf[c], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Dc + (qfo ^ (32 * c))), vf[c], dp, 0, 0, 0);
+        }
+        const bool interior = i0 + 31 < a.Sq && (!a.causal || kw + 31 <= i0 + off);  // whole 32x32 block visible (key validity is per lane)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
+            const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const int i = i0 + 8 * g + 4 * h2 + e;
+                const bool ok = kok && (interior || (i < a.Sq && (!a.causal || kj <= i + off)));
+                const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc2, bias2 - lv[e])) : 0.f;
+                s[r] = p;
+                dp[r] = p * (dp[r] - dvv[e]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bf16x8_t pf = pack8(s, 8 * c), dsf = pack8(dp, 8 * c);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Dc, to1, to2, db, 16 * c), pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Qc, to1, to2, db, 16 * c), dsf, dk[db], 0, 0, 0);
+            }
+        }
+    }
+    if (kj < a.Sk) {
+        store_dt(a.dk + b * a.dks.b + hd * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, h2);
+        store_dt(a.dv + b * a.dvs.b + hd * a.dvs.h + (int64_t)kj * a.dvs.s, dv, 1.0f, h2);
+    }
+}
+
 int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
     OTTER_REQUIRE(d && d->q && d->k && d->v && d->o && d->lse, "flash: null pointer");
     OTTER_REQUIRE(d->head_dim == HD, "flash: head_dim %d (only 128)", d->head_dim);
@@ -523,6 +933,8 @@ int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
     return OTTER_OK;
 }
 
+int g_flash_variant = 0;
+
 template <typename K>
 int set_smem(K kern, int bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -534,14 +946,29 @@ int set_smem(K kern, int bytes) {
 
 extern "C" {
 
+int otter_flash_set_variant(int v) {
+    OTTER_REQUIRE(v >= 0 && v <= 2, "flash variant %d (0 = default, 1 = register-staged v1, 2 = LDS-DMA v2)", v);
+    g_flash_variant = v;
+    return OTTER_OK;
+}
+
 int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
     FlashArgs a;
     int rc = fill_args(d, a, false);
     if (rc) return rc;
-    const int smem = 64 * LDK * 2 + 64 * LDT * 2;
-    static bool once = false;
-    if (!once) { rc = set_smem(flash_fwd_kernel, smem); if (rc) return rc; once = true; }
-    hipLaunchKernelGGL(flash_fwd_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
+    // the DMA path addresses a head's K / V with 32-bit offsets from its base
+    const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < (int64_t(1) << 31) && (int64_t)a.Sk * a.vs.s * 2 < (int64_t(1) << 31);
+    if (v2) {
+        const int smem = 65536;
+        static bool once = false;
+        if (!once) { rc = set_smem(flash_fwd2_kernel, smem); if (rc) return rc; once = true; }
+        hipLaunchKernelGGL(flash_fwd2_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
+    } else {
+        const int smem = 64 * LDK * 2 + 64 * LDT * 2;
+        static bool once = false;
+        if (!once) { rc = set_smem(flash_fwd_kernel, smem); if (rc) return rc; once = true; }
+        hipLaunchKernelGGL(flash_fwd_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
+    }
     OTTER_CHECK_LAUNCH("flash_fwd");
     return OTTER_OK;
 }
@@ -554,6 +981,23 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
     hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, st, a);
     OTTER_CHECK_LAUNCH("flash_delta");
+    const int64_t lim = int64_t(1) << 31;
+    const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < lim && (int64_t)a.Sk * a.vs.s * 2 < lim &&
+                    (int64_t)a.Sq * a.qs.s * 2 < lim && (int64_t)a.Sq * a.dos.s * 2 < lim;
+    if (v2) {
+        const int smem_kv = 32768 + 1024, smem_q = 65536;
+        static bool once = false;
+        if (!once) {
+            rc = set_smem(flash_bwd_dkv2_kernel, smem_kv); if (rc) return rc;
+            rc = set_smem(flash_bwd_dq2_kernel, smem_q); if (rc) return rc;
+            once = true;
+        }
+        hipLaunchKernelGGL(flash_bwd_dkv2_kernel, dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), smem_kv, st, a);
+        OTTER_CHECK_LAUNCH("flash_bwd_dkv");
+        hipLaunchKernelGGL(flash_bwd_dq2_kernel, dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), smem_q, st, a);
+        OTTER_CHECK_LAUNCH("flash_bwd_dq");
+        return OTTER_OK;
+    }
     const int smem_kv = (2 * 32 * LDK + 2 * 32 * LDT) * 2 + 64 * 4;
     const int smem_q = (2 * 64 * LDK + 64 * LDT) * 2;
     static bool once = false;

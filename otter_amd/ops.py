@@ -309,7 +309,7 @@ def flash_attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, slopes, key_valid, scale, 
     """Writes dq / dk / dv (caller-provided [B,S,H,128] views, e.g. the three slices of one dqkv buffer)."""
     K.require_cuda(dout, dq, dk, dv)
     d = _flash_desc(q, k, v, o, lse, slopes, key_valid, scale, causal)
-    delta = torch.empty_like(lse)
+    delta = torch.empty((2,) + tuple(lse.shape), dtype=torch.float32, device=lse.device)  # row dots + log2-domain lse
     d.dout, d.dov = dout.data_ptr(), _flash_view(dout)
     d.delta = delta.data_ptr()
     d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
@@ -343,6 +343,11 @@ def add_rows_(dst2d, src2d, src_map: RowMap):
     assert dst2d.is_contiguous() and src2d.is_contiguous() and dst2d.dtype == src2d.dtype
     K.check(K.lib().otter_add_rows(dst2d.data_ptr(), src2d.data_ptr(), src_map, rows, D, K.dt(dst2d), K.stream()), "add_rows")
     return dst2d
+
+
+def set_flash_variant(v: int):
+    """0 = default, 1 = register-staged tiles, 2 = LDS-DMA tiles (A/B hook of the decoder-host flash attention)."""
+    K.check(K.lib().otter_flash_set_variant(int(v)), "flash_set_variant")
 
 
 def set_gemm_variant(v: int):

@@ -51,9 +51,12 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("B,H,S,causal,alibi,lens", CASES)
-def test_flash_attention_fwd_bwd(ops, B, H, S, causal, alibi, lens):
+def test_flash_attention_fwd_bwd(ops, B, H, S, causal, alibi, lens, variant):
     from otter_amd.mpt import alibi_slopes
+
+    ops.set_flash_variant(variant)
 
     qkv, dout, valid = _case(B * 1000 + S, B, H, S, lens)
     slopes = alibi_slopes(H, 8).float() if alibi else None
@@ -66,6 +69,7 @@ def test_flash_attention_fwd_bwd(ops, B, H, S, causal, alibi, lens):
     dqkv = torch.full_like(dq5, float("nan"))
     ops.flash_attn_bwd(q, k, v, o, lse, dout.to(DEV), dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], sl, kvd, scale, causal)
     torch.cuda.synchronize()
+    ops.set_flash_variant(0)
 
     f = lambda t: t.double().numpy().transpose(0, 2, 1, 3)  # [B,S,H,d] -> [B,H,S,d]
     qh, kh, vh = f(qkv[:, :, 0].float()), f(qkv[:, :, 1].float()), f(qkv[:, :, 2].float())
@@ -110,8 +114,13 @@ def test_flash_batch_rows_independent(ops):
     pert = qkv.clone()
     pert[:, 300:] = torch.randn_like(pert[:, 300:])
     o2, _ = ops.flash_attn_fwd(pert[:, :, 0], pert[:, :, 1], pert[:, :, 2], sl, None, scale, True)
-    # ALiBi is anchored at the LAST key (j - (Sk-1)), but a row's softmax is invariant to the per-row constant shift
-    assert torch.equal(o[:, :300], o2[:, :300])
+    # ALiBi is anchored at the LAST key (j - (Sk-1)), but a row's softmax is invariant to the per-row constant shift.
+    # Rows whose 32-row wave lies entirely before the perturbation are bit-identical; rows 288..299 share a wave with
+    # perturbed rows, and the wave-uniform lazy-rescale decision may then fall on a different tile: same value, possibly a
+    # different rounding of P and of the result (bf16): equal to rounding error, not bit for bit.
+    assert torch.equal(o[:, :288], o2[:, :288])
+    a_, b_ = o[:, 288:300].float(), o2[:, 288:300].float()
+    assert float((a_ - b_).abs().max()) <= 1e-2 * float(b_.abs().max())
 
 
 def test_mpt_host_flash_matches_sdpa_path(ops, monkeypatch):

@@ -28,7 +28,8 @@ scale = 1 / math.sqrt(128)
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
 o, lse = ops.flash_attn_fwd(q, k, v, sl, None, scale, CAUSAL)
 dqkv = torch.empty_like(qkv)
-res = {"B": B, "S": S, "H": H, "causal": CAUSAL}
+ops.set_flash_variant(int(os.environ.get("FLASH_VARIANT", "0")))
+res = {"B": B, "S": S, "H": H, "causal": CAUSAL, "variant": int(os.environ.get("FLASH_VARIANT", "0"))}
 res["hip_fwd_us"] = bench(lambda: ops.flash_attn_fwd(q, k, v, sl, None, scale, CAUSAL))
 res["hip_bwd_us"] = bench(lambda: ops.flash_attn_bwd(q, k, v, o, lse, dout, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], sl, None, scale, CAUSAL))
 fl = 4 * B * H * S * S * 128 * (0.5 if CAUSAL else 1.0)
