@@ -231,6 +231,31 @@ int otter_add_frame_embs(void* x, int x_dtype, const float* emb, int64_t outer, 
 int otter_add_rows(void* dst, const void* src, otter_rowmap src_map, int64_t rows, int64_t D, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Optimizer step of the recipe: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by
+ * torch.optim.AdamW.step()          /root/reference/pipeline/train/instruction_following.py:246-251
+ * as two sweeps: otter_grad_sumsq (+ otter_clip_coef -> {norm, coefficient} on the device) and otter_adamw_step, which
+ * multiplies the gradients by *grad_scale on the fly (the scaled gradients are NOT written back), follows torch's
+ * fused AdamW arithmetic (decoupled weight decay, lerp first moment, bias corrections passed in) and optionally
+ * refreshes a bf16 copy of each parameter.  `tensors` is a DEVICE array; block i of the launch owns elements
+ * [blk_chunk[i] * otter_adamw_chunk(), ...) of tensors[blk_tensor[i]].
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct otter_adamw_tensor {
+    float* p; const float* g; float* m; float* v;
+    uint16_t* shadow;      /* bf16 copy of p, or NULL */
+    int64_t numel;
+    float weight_decay;
+    int32_t reserved;
+} otter_adamw_tensor;
+
+int otter_adamw_chunk(void);
+int otter_grad_sumsq(const otter_adamw_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk, int64_t nblocks,
+                     float* partials, void* stream);
+int otter_clip_coef(const float* partials, int64_t n, float max_norm, float* out2, void* stream);
+int otter_adamw_step(const otter_adamw_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk, int64_t nblocks, float lr,
+                     float beta1, float beta2, float eps, float bias_correction1, float bias_correction2, const float* grad_scale,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Profiling hook used by bench.py for the `roofline` object: when enabled, every launch of the bf16 GEMM whose
  * (M,N,K) equals the armed shape is bracketed by hipEvents on the launch stream; otter_prof_collect waits for
  * them and returns count and total milliseconds.

@@ -90,6 +90,10 @@ SIGNATURES = {
     "otter_flash_attn_fwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_flash_attn_bwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_flash_set_variant": (_int, [_int]),
+    "otter_adamw_chunk": (_int, []),
+    "otter_grad_sumsq": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "otter_clip_coef": (_int, [_vp, _i64, _f32, _vp, _vp]),
+    "otter_adamw_step": (_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "otter_prof_arm_gemm": (_int, [_i64, _i64, _i64, _int]),
     "otter_prof_disarm": (_int, []),
     "otter_prof_collect": (_int, [C.POINTER(_int), C.POINTER(C.c_double)]),

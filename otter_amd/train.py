@@ -8,6 +8,7 @@ bench.py and the tests can drive one step without the reference's dataset / acce
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -57,7 +58,7 @@ class TrainStep:
 
     def __init__(self, model, lr: float = 1e-5, weight_decay: float = 0.1, max_grad_norm: float = 1.0,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, process_group=None, bucket_bytes: int = 640 << 20,
-                 fused_optimizer: bool = True, force_reducer: bool = False):
+                 fused_optimizer: bool = True, force_reducer: bool = False, hip_optimizer: Optional[bool] = None):
         self.model = model
         self.max_grad_norm = max_grad_norm
         self.autocast_dtype = autocast_dtype
@@ -65,7 +66,16 @@ class TrainStep:
         groups = [{"params": [p for p in g["params"] if p.requires_grad], "weight_decay": g["weight_decay"]} for g in groups]
         self.params = [p for g in groups for p in g["params"]]
         dev = self.params[0].device
-        self.optimizer = torch.optim.AdamW(groups, lr=lr, fused=bool(fused_optimizer and dev.type == "cuda"))
+        # GPU: clip + AdamW as two HIP sweeps (otter_amd/optim.py); CPU (gloo tests) or OTTER_TORCH_ADAMW=1: torch.optim.AdamW
+        if hip_optimizer is None:
+            hip_optimizer = dev.type == "cuda" and os.environ.get("OTTER_TORCH_ADAMW") != "1"
+        self.hip_optimizer = bool(hip_optimizer)
+        if self.hip_optimizer:
+            from .optim import FusedAdamW
+
+            self.optimizer = FusedAdamW(groups, lr=lr, max_grad_norm=max_grad_norm)
+        else:
+            self.optimizer = torch.optim.AdamW(groups, lr=lr, fused=bool(fused_optimizer and dev.type == "cuda"))
         self.world = torch.distributed.get_world_size(process_group) if torch.distributed.is_initialized() else 1
         # single rank: gradients stay ordinary .grad tensors (no bucket indirection, nothing to reduce)
         self.reducer = GradReducer(self.params, bucket_bytes, process_group, force=force_reducer) if (self.world > 1 or force_reducer) else None
@@ -88,7 +98,7 @@ class TrainStep:
         loss.backward()
         if self.reducer is not None:
             self.reducer.wait()
-        if self.max_grad_norm is not None:
+        if self.max_grad_norm is not None and not self.hip_optimizer:
             torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
-        self.optimizer.step()
+        self.optimizer.step()   # the HIP optimizer clips inside its step
         return loss.detach()
