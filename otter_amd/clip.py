@@ -101,9 +101,33 @@ class _VisionTransformer(nn.Module):
 
     def forward(self, pixel_values):
         x = self.pre_layrnorm(self.embeddings(pixel_values))
+        if x.is_cuda and not torch.is_grad_enabled():
+            return self._forward_fused(x)
         for layer in self.encoder.layers:
             x = layer(x)
         return x  # last_hidden_state: post_layernorm applies to the pooled CLS only (clip.py:434-436)
+
+    def _forward_fused(self, x):
+        """Inference path of the frozen tower (the recipe runs it under no_grad, modeling_otter.py:990-991): every residual add
+        is folded into the following LayerNorm pass (otter_add_layernorm_fwd), 2 launches per layer instead of 4.  Same
+        values: the sum keeps the residual stream's dtype, the normalised rows are rounded once to the GEMM operand dtype."""
+        from . import functional as OF
+        from . import ops
+
+        shp = x.shape
+        cd = OF.compute_dtype_for(x)
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        delta = None
+        for layer in self.encoder.layers:
+            n1, n2 = layer.layer_norm1, layer.layer_norm2
+            if delta is None:
+                a = ops.layernorm_fwd(x2, n1.weight, n1.bias, cd, n1.eps, need_stats=False)[0]
+            else:
+                x2, a, _, _ = ops.add_layernorm_fwd(x2, delta, n1.weight, n1.bias, cd, n1.eps, need_stats=False)
+            b = layer.self_attn(a.view(shp)).reshape(-1, shp[-1])
+            x2, m, _, _ = ops.add_layernorm_fwd(x2, b.contiguous(), n2.weight, n2.bias, cd, n2.eps, need_stats=False)
+            delta = layer.mlp(m.view(shp)).reshape(-1, shp[-1]).contiguous()
+        return (x2 + delta).view(shp)
 
 
 class CLIPVisionModel(nn.Module):

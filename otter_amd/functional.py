@@ -62,9 +62,22 @@ class _Shadows:
     def wt(self, p: torch.Tensor, cd) -> torch.Tensor:
         t = self._valid(self._wt, p, cd)
         if t is None:
-            t = ops.transpose(p.detach(), cd)
+            # transposing the cd-typed copy (when it is current) reads half the bytes and gives the same bits
+            src = self._valid(self._w, p, cd) if p.dtype != cd else None
+            t = ops.transpose(src if src is not None else p.detach(), cd)
             self._wt[self._key(p, cd)] = (weakref.ref(p), p._version, p.data_ptr(), t)
         return t
+
+    # ---- hooks for an optimizer that refreshes the cd-typed copy inside its own update kernel (otter_amd/optim.py) ----
+    def stale_w(self, p: torch.Tensor, cd):
+        """The cached copy's storage (whatever its version), so the optimizer can overwrite it in place; None if absent."""
+        ent = self._w.get(self._key(p, cd))
+        if ent is None or ent[0]() is not p or ent[2] != p.data_ptr() or not ent[3].is_contiguous():
+            return None
+        return ent[3]
+
+    def mark_w(self, p: torch.Tensor, cd, t: torch.Tensor):
+        self._w[self._key(p, cd)] = (weakref.ref(p), p._version, p.data_ptr(), t)
 
     def clear(self):
         self._w.clear()

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _capi as K
+from .functional import shadows
 
 _META = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("shadow", "<u8"), ("numel", "<i8"),
                   ("weight_decay", "<f4"), ("reserved", "<i4")])
@@ -32,6 +33,7 @@ class FusedAdamW:
             pg["params"] = [p for p in pg["params"]]
             self.param_groups.append(pg)
         self.max_grad_norm = max_grad_norm
+        self.refresh_shadows = True
         self.state = {}
         self._step = 0
         self._tables = None
@@ -103,6 +105,9 @@ class FusedAdamW:
             self._build(live)
         t = self._tables
         t["meta"]["g"] = [p.grad.data_ptr() for p, _ in live]
+        # parameters that have a bf16 copy in the GEMM operand cache get it refreshed by the update kernel itself
+        sh = [shadows.stale_w(p, torch.bfloat16) if self.refresh_shadows else None for p, _ in live]
+        t["meta"]["shadow"] = [0 if x is None else x.data_ptr() for x in sh]
         t["hmeta"].numpy()[:] = t["meta"].view(np.uint8)
         t["dmeta"].copy_(t["hmeta"], non_blocking=True)
         self._step += 1
@@ -120,5 +125,7 @@ class FusedAdamW:
                                      scale, st), "adamw_step")
         # the parameters changed in place behind autograd's back: bump the version counters the bf16 shadow cache keys on
         # (functional._Shadows) -- host-side bookkeeping only, no kernel
-        for p, _ in live:
+        for (p, _), x in zip(live, sh):
             torch.autograd.graph.increment_version(p)
+            if x is not None:
+                shadows.mark_w(p, torch.bfloat16, x)
