@@ -7,8 +7,9 @@ The reference gets its all-reduce implicitly from accelerate -> torch DDP (instr
     tied embedding = 5.54 GB fp32), and xGMI is a point-to-point mesh (7 links x ~153 GB/s) where a ring all-reduce is
     per-link bound -- so buckets are BIG (default 640 MB = one gated cross-attention block): 10 large collectives
     instead of ~220 small ones;
-  * parameters' .grad tensors are *views into the flat bucket*, so autograd accumulates straight into the communication
-    buffer (no grad->bucket copy, no bucket->grad copy-back) and the optimizer reads the reduced values in place;
+  * parameters' .grad tensors are *views into the flat bucket*: the weight-gradient GEMMs of the hand-written path write
+    their result straight into that view (functional.grad_sink: no zero-fill, no accumulate pass, no copy), gradients
+    produced by stock autograd (the tied embedding) are copied in once, and the optimizer reads the reduced values in place;
   * a bucket's all-reduce is launched (async, on RCCL's stream) from the post-accumulate-grad hook of its last-arriving
     parameter, i.e. while the frozen decoder layers *below* that cross-attention block are still running their dgrad --
     the overlap window of SURVEY.md section 5.
@@ -25,13 +26,14 @@ import torch.distributed as dist
 class _Bucket:
     def __init__(self, params: List[torch.nn.Parameter], dtype, device):
         self.params = params
-        n = sum(p.numel() for p in params)
-        self.flat = torch.zeros(n, dtype=dtype, device=device)
-        self.views = []
-        off = 0
+        # every slice starts on a 256-byte boundary: the weight-gradient GEMMs store into the views with 16-byte vectors
+        al = 256 // torch.empty((), dtype=dtype).element_size()
+        offs, off = [], 0
         for p in params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            offs.append(off)
+            off += (p.numel() + al - 1) // al * al
+        self.flat = torch.zeros(off, dtype=dtype, device=device)   # padding stays zero (zeros reduce to zeros)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
         self.pending = len(params)
         self.work = None
 
@@ -63,32 +65,59 @@ class GradReducer:
         self._owner = {}
         self._view = {}
         self._hooks = []
+        self._written = set()   # id(param) whose bucket view holds this step's gradient
         self.sync = True
         for b in self.buckets:
             for p, v in zip(b.params, b.views):
                 if p.dtype != grad_dtype:
                     raise ValueError("GradReducer: parameter dtype must equal grad_dtype (fp32 master weights)")
-                p.grad = v
+                p.grad = None
                 self._owner[p] = b
                 self._view[p] = v
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        from . import functional as _F
+
+        _F.grad_sink = self  # weight-gradient GEMMs now target the bucket views directly
 
     # ---- step protocol:  zero_grad() ... backward() ... wait() ... optimizer.step() ----
     def zero_grad(self):
+        """No memset: every view is either overwritten by its first gradient of the step or zeroed in wait()."""
+        self._written.clear()
         for b in self.buckets:
-            b.flat.zero_()
             b.pending = len(b.params)
             b.work = None
-            for p, v in zip(b.params, b.views):
-                p.grad = v  # in case something replaced it (e.g. optimizer.zero_grad(set_to_none=True))
+            for p in b.params:
+                p.grad = None
+
+    # ---- grad sink protocol (otter_amd.functional._wgrad) ----
+    def take(self, p: torch.nn.Parameter):
+        """The bucket view to write p's gradient into (overwrite semantics), or None if this step already put one there
+        (micro-batch accumulation: the caller then returns its gradient to autograd, which adds it in place)."""
+        if p not in self._owner or id(p) in self._written:
+            return None
+        self._written.add(id(p))
+        return self._view[p]
+
+    def ready(self, p: torch.nn.Parameter):
+        p.grad = self._view[p]
+        self._count(p)
 
     def _on_grad(self, p: torch.nn.Parameter):
-        b = self._owner[p]
         v = self._view[p]
         if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-            # autograd installed a fresh tensor (grad was None): fold it into the bucket view
-            v.add_(p.grad)
+            # autograd installed a fresh tensor (grad was None): move it into the bucket view
+            if id(p) in self._written:
+                v.add_(p.grad)
+            else:
+                v.copy_(p.grad)
+                self._written.add(id(p))
             p.grad = v
+        else:
+            self._written.add(id(p))  # accumulated in place into the view
+        self._count(p)
+
+    def _count(self, p: torch.nn.Parameter):
+        b = self._owner[p]
         b.pending -= 1
         if b.pending == 0 and self.sync and (self.world > 1 or self.force):
             self._launch(b)
@@ -104,6 +133,12 @@ class GradReducer:
     def wait(self):
         """Block the current stream until every bucket is reduced.  Buckets whose hooks never fired (unused parameters)
         are reduced here so that all ranks issue the same collectives."""
+        for b in self.buckets:  # parameters that produced no gradient this step contribute zeros
+            for p, v in zip(b.params, b.views):
+                if id(p) not in self._written:
+                    v.zero_()
+                    self._written.add(id(p))
+                    p.grad = v
         if (self.world > 1 or self.force) and self.sync:
             for b in self.buckets:
                 if b.work is None:
@@ -115,6 +150,16 @@ class GradReducer:
                     b._needs_div = False
         for b in self.buckets:
             b.pending = len(b.params)
+
+    def close(self):
+        """Detach from autograd and from the weight-gradient GEMMs (the parameters keep their current .grad views)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        from . import functional as _F
+
+        if _F.grad_sink is self:
+            _F.grad_sink = None
 
     def no_sync(self):
         red = self

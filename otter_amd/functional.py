@@ -87,8 +87,20 @@ class _Shadows:
 shadows = _Shadows()
 
 
-def _wgrad(dyT: torch.Tensor, xT: torch.Tensor, gate=None) -> torch.Tensor:
-    """dW[out,in] = (s *) dy^T . x   from the two transposed, zero-padded operands (fp32 result)."""
+# Set by dp.GradReducer: lets a weight gradient be written by its GEMM straight into the parameter's slice of the flat
+# communication bucket (no zero-fill + accumulate pass, no copy).  Interface: take(param) -> fp32 view or None,
+# ready(param).
+grad_sink = None
+
+
+def _wgrad(dyT: torch.Tensor, xT: torch.Tensor, gate=None, param=None):
+    """dW[out,in] = (s *) dy^T . x   from the two transposed, zero-padded operands (fp32 result).  With a grad sink and
+    `param`, the result lands in the sink's buffer and None is returned (autograd then has nothing to accumulate)."""
+    out = grad_sink.take(param) if (grad_sink is not None and param is not None) else None
+    if out is not None:
+        ops.gemm_nt(dyT, xT, out=out, kind=EPI_STORE, gate=gate)
+        grad_sink.ready(param)
+        return None
     return ops.gemm_nt(dyT, xT, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
 
 
@@ -241,7 +253,8 @@ class LinearFn(torch.autograd.Function):
         dx = ops.gemm_nt(dy, shadows.wt(W, cd)) if ctx.needs_input_grad[0] else None
         dW = None
         if ctx.needs_input_grad[1]:
-            dW = _wgrad(ops.transpose(dy, cd), ops.transpose(x2, cd)).to(W.dtype)
+            dW = _wgrad(ops.transpose(dy, cd), ops.transpose(x2, cd), param=W)
+            dW = dW.to(W.dtype) if dW is not None else None
         return dx, dW
 
 
@@ -373,8 +386,8 @@ class GatedCrossAttentionFn(torch.autograd.Function):
         part = torch.empty(ops.gemm_num_partials(N, W1.shape[0], cd), dtype=torch.float32, device=dev)
         dU = ops.gemm_nt(dy_cd, shadows.wt(W2, cd), kind=EPI_GATE_BWD, gate=gf, aux=u, aux_gelu=True, partial=part)
         d_ff_gate = ops.reduce_partials(part, gate=gf)
-        dW2 = _wgrad(dyT, ops.transpose(h, cd), gate=gf)
-        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd))
+        dW2 = _wgrad(dyT, ops.transpose(h, cd), gate=gf, param=W2)
+        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd), param=W1)
         df = ops.gemm_nt(dU, shadows.wt(W1, cd))
         dx1, dg2, db2 = ops.layernorm_bwd(df, x1, ffn_w.detach(), mean2, rstd2, rd, dres=dy2)
         # ---- attention branch:  x1 = (o Wo^T) tanh(ga) + x ----
@@ -382,20 +395,22 @@ class GatedCrossAttentionFn(torch.autograd.Function):
         part2 = torch.empty(ops.gemm_num_partials(N, inner, cd), dtype=torch.float32, device=dev)
         dO = ops.gemm_nt(dx1_cd, shadows.wt(Wo, cd), kind=EPI_GATE_BWD, gate=ga, aux=o2, aux_gelu=False, partial=part2)
         d_attn_gate = ops.reduce_partials(part2, gate=ga)
-        dWo = _wgrad(dx1T, ops.transpose(o2, cd), gate=ga)
+        dWo = _wgrad(dx1T, ops.transpose(o2, cd), gate=ga, param=Wo)
         kv3 = kv.view(B, M, 2 * inner)
         dq, dkv = ops.attn_bwd(q.view(B, T, inner), kv3[..., :inner], kv3[..., inner:], o2.view(B, T, inner),
                                dO.view(B, T, inner), lse, heads, tt, n, mask_mode, scale)
         dq2, dkv2 = dq.view(N, inner), dkv.view(B * M, 2 * inner)
-        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(xn, cd))
+        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(xn, cd), param=Wq)
         dxn = ops.gemm_nt(dq2, shadows.wt(Wq, cd))
-        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(med, cd))
+        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(med, cd), param=Wkv)
         dmedia = None
         if ctx.needs_input_grad[1]:
             dmedia = ops.gemm_nt(dkv2, shadows.wt(Wkv, cd), out_dtype=media_dtype).view(B, T_img, n, Dv)
         dx, dg1, db1 = ops.layernorm_bwd(dxn, x2, norm_w.detach(), mean1, rstd1, rd, dres=dx1)
 
         def pg(g, p):
+            if g is None:  # already delivered through the grad sink
+                return None
             return g.to(p.dtype) if g.dtype != p.dtype else g
 
         return (dx.view(B, T, D), dmedia, None, None, None, None, pg(dg1, norm_w), pg(db1, norm_w), pg(dWq, Wq), pg(dWkv, Wkv),
@@ -456,20 +471,20 @@ class PerceiverBlockFn(torch.autograd.Function):
         # feed-forward: y = gelu(f W1^T) W2^T + out1
         dyT, dy_cd = ops.transpose(dy2, cd, want_same=True)
         dU = ops.gemm_nt(dy_cd, shadows.wt(W2, cd), kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
-        dW2 = _wgrad(dyT, ops.transpose(h, cd))
-        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd))
+        dW2 = _wgrad(dyT, ops.transpose(h, cd), param=W2)
+        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd), param=W1)
         df = ops.gemm_nt(dU, shadows.wt(W1, cd))
         dout1, dgf, dbf = ops.layernorm_bwd(df, out1, ff_w.detach(), mean_f, rstd_f, rd, dres=dy2)
         # attention: out1 = o Wo^T + latents
         d1T, d1_cd = ops.transpose(dout1, cd, want_same=True)
         dO = ops.gemm_nt(d1_cd, shadows.wt(Wo, cd))
-        dWo = _wgrad(d1T, ops.transpose(o2, cd))
+        dWo = _wgrad(d1T, ops.transpose(o2, cd), param=Wo)
         kv3 = kv.view(G, nk, 2 * inner)
         dq, dkv = ops.attn_bwd(q.view(G, n2, inner), kv3[..., :inner], kv3[..., inner:], o2.view(G, n2, inner),
                                dO.view(G, n2, inner), lse, heads, None, 1, MASK_NONE, scale)
         dq2, dkv2 = dq.view(G * n2, inner), dkv.view(G * nk, 2 * inner)
-        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(ln, cd))
-        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(kv_in, cd))
+        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(ln, cd), param=Wq)
+        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(kv_in, cd), param=Wkv)
         dkv_in = ops.gemm_nt(dkv2, shadows.wt(Wkv, cd))                            # [G*nk, D] grads of [xn ; ln]
         # d(ln) = dq Wq (through to_q) + the latent rows of dkv_in (through to_kv)
         dln = ops.gemm_nt(dq2, shadows.wt(Wq, cd))
@@ -484,6 +499,8 @@ class PerceiverBlockFn(torch.autograd.Function):
             dx = dxm.view(G, n1, D)
 
         def pg(g, p):
+            if g is None:  # already delivered through the grad sink
+                return None
             return g.to(p.dtype) if g.dtype != p.dtype else g
 
         return (dx, dl.view(G, n2, D), None, None, pg(dgm, nm_w), pg(dbm, nm_w), pg(dgl, nl_w), pg(dbl, nl_w), pg(dWq, Wq),
