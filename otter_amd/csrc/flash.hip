@@ -795,7 +795,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
 }
 
 __global__ __launch_bounds__(256) void flash_bwd_dkv2_kernel(FlashArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // Q0 | Q1 | dO0 | dO1 (8 KB each) | lse2[2][64] | delta[2][64]
+    // 3-stage ring, two query tiles in flight (a 32-row tile is only ~1k MFMA cycles of work, less than the DMA latency):
+    // Q[3] | dO[3] (8 KB each) | lse2[3][64] | delta[3][64]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, hd = blockIdx.y, k0 = blockIdx.x * 128;
@@ -837,18 +839,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv2_kernel(FlashArgs a) {
         vq[i] = (uint32_t)rl * qrow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
         vd[i] = (uint32_t)rl * dorow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
     }
-    char* const stat = smem + 32768;
+    char* const stat = smem + 49152;
     auto issue = [&](int qt, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(smem + buf * 8192 + (wave * 2 + i) * 1024), 16,
                                                      (int)vq[i], (int)((uint32_t)qt * 32u * qrow), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(smem + 16384 + buf * 8192 + (wave * 2 + i) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(smem + 24576 + buf * 8192 + (wave * 2 + i) * 1024), 16,
                                                      (int)vd[i], (int)((uint32_t)qt * 32u * dorow), 0, 0);
         }
         if (wave == 0) {  // 64 floats each (the upper 32 belong to the next tile; rows past Sq read as 0 and are masked)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rls, (__attribute__((address_space(3))) void*)(stat + buf * 256), 4, lane * 4, qt * 128, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, (__attribute__((address_space(3))) void*)(stat + 512 + buf * 256), 4, lane * 4, qt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, (__attribute__((address_space(3))) void*)(stat + 768 + buf * 256), 4, lane * 4, qt * 128, 0, 0);
         }
     };
     const int qfo = ql * 256 + ((h2 ^ pi16(ql & 15)) << 4);
@@ -858,18 +860,26 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv2_kernel(FlashArgs a) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
     if (qt0 < nqt) issue(qt0, 0);
-    for (int qt = qt0; qt < nqt; ++qt) {
-        const int cur = (qt - qt0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    if (qt0 + 1 < nqt) issue(qt0 + 1, 1);
+    int cur = 0;
+    for (int qt = qt0; qt < nqt; ++qt, cur = cur == 2 ? 0 : cur + 1) {
+        // tile qt has landed when at most the pieces of tile qt+1 are outstanding (wave 0 also carries the two statistics pieces)
+        if (qt + 1 < nqt) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done with tile qt-1, whose slot is refilled next
         asm volatile("" ::: "memory");
-        if (qt + 1 < nqt) issue(qt + 1, cur ^ 1);
+        if (qt + 2 < nqt) issue(qt + 2, cur == 0 ? 2 : cur - 1);
         const int i0 = qt * 32;
-        if (a.causal && i0 + 31 + off < kw) continue;  // every query of the tile precedes this wave's keys
+        // (no per-wave skip of tiles that precede the wave's keys: the branch makes hipcc shuttle the 128 accumulator
+        //  registers between VGPRs and AGPRs on every iteration, which costs more than the <= 3 masked tiles it saves)
         const char* Qc = smem + cur * 8192;
-        const char* Dc = smem + 16384 + cur * 8192;
+        const char* Dc = smem + 24576 + cur * 8192;
         const float* lse_s = reinterpret_cast<const float*>(stat + cur * 256);
-        const float* dl_s = reinterpret_cast<const float*>(stat + 512 + cur * 256);
+        const float* dl_s = reinterpret_cast<const float*>(stat + 768 + cur * 256);
         f32x16_t s = zero16(), dp = zero16();
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -985,7 +995,7 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
     const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < lim && (int64_t)a.Sk * a.vs.s * 2 < lim &&
                     (int64_t)a.Sq * a.qs.s * 2 < lim && (int64_t)a.Sq * a.dos.s * 2 < lim;
     if (v2) {
-        const int smem_kv = 32768 + 1024, smem_q = 65536;
+        const int smem_kv = 49152 + 1536, smem_q = 65536;
         static bool once = false;
         if (!once) {
             rc = set_smem(flash_bwd_dkv2_kernel, smem_kv); if (rc) return rc;
