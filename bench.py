@@ -223,7 +223,7 @@ def main():
             # HBM-side traffic per launch comes from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
             # WRITE_SIZE) committed under profiles/; PMC collection cannot share a run with the timed region.
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_ffn.json")
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_ffn_v13.json")
             if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
                 with open(pmc) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
