@@ -5,6 +5,7 @@ happens in libotter_hip.so.  Every wrapper validates devices/dtypes/contiguity a
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -31,6 +32,16 @@ class _Workspace:
 
 
 _ws = _Workspace()
+
+
+# OTTER_GEMM_LOG=1: count the GEMM shapes of a run and print them at exit (tuning aid)
+_GEMM_LOG = None
+if os.environ.get("OTTER_GEMM_LOG") == "1":
+    import atexit
+    import collections
+
+    _GEMM_LOG = collections.Counter()
+    atexit.register(lambda: print("\n".join("gemm M=%d N=%d K=%d epi=%d %s->%s  x%d" % (k + (v,)) for k, v in sorted(_GEMM_LOG.items()))))
 
 
 def _c2d(t: torch.Tensor) -> torch.Tensor:
@@ -169,6 +180,8 @@ def gemm_nt(A, B, out_dtype=None, out=None, kind=EPI_STORE, gate=None, R=None, C
         e.aux, e.ldaux, e.aux_dtype = aux.data_ptr(), aux.stride(0), K.dt(aux)
     e.aux_is_gelu_input = 1 if aux_gelu else 0
     e.partial = K.ptr(partial)
+    if _GEMM_LOG is not None:
+        _GEMM_LOG[(M, N, Kd, kind, str(A.dtype).split(".")[-1], str(out.dtype).split(".")[-1])] += 1
     K.check(K.lib().otter_gemm_nt(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0), M, N, Kd,
                                   K.dt(A), K.dt(out), C.byref(e), K.stream()), "gemm_nt")
     return out
