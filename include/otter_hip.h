@@ -167,6 +167,9 @@ int otter_attn_fwd(const void* q, int64_t q_stride, const void* k, const void* v
                    int64_t o_stride, float* lse, const int32_t* text_time, int64_t B, int64_t H, int64_t Tq, int64_t M,
                    int64_t n_per_media, int mask_mode, float scale, int dtype, void* stream);
 
+/* tuning / A-B hook: 0 = MFMA kernels for bf16 inputs (attn_mfma.hip), 1 = fp32 VALU kernels for every dtype */
+int otter_attn_set_variant(int variant);
+
 int64_t otter_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t Tq, int64_t M);
 /* dq like q; dk/dv like k/v (stride dkv_stride).  ws from otter_attn_bwd_workspace_bytes. */
 int otter_attn_bwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t kv_stride, const void* o,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "otter_text_time": (_int, [_vp, _vp, _i64, _i64, _int, _vp]),
     "otter_attn_fwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _f32, _int,
                               _vp]),
+    "otter_attn_set_variant": (_int, [_int]),
     "otter_attn_bwd_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "otter_attn_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64,
                               _i64, _i64, _i64, _int, _f32, _int, _vp]),

@@ -14,9 +14,20 @@
 
 #include "common.h"
 
+// MFMA implementation of the same entry points for bf16 (attn_mfma.hip)
+namespace otter_xattn {
+bool eligible(int dtype, int mask_mode, int64_t n_per_media, int64_t q_stride, int64_t kv_stride, const void* q, const void* k, const void* v);
+int fwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t kv_stride, void* o, int64_t o_stride, float* lse,
+        const int32_t* tt, int64_t B, int64_t H, int64_t Tq, int64_t M, int64_t npm, int mode, float scale, hipStream_t st);
+int bwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t kv_stride, const void* o, const void* d_o, int64_t o_stride,
+        const float* lse, const int32_t* tt, void* dq, int64_t dq_stride, float* delta, float* part_k, float* part_v, int64_t B, int64_t H,
+        int64_t Tq, int64_t M, int64_t npm, int mode, float scale, hipStream_t st);
+}  // namespace otter_xattn
+
 namespace {
 
 constexpr int HD = 64;  // head dim
+int g_attn_variant = 0;  // 0 = MFMA kernels for bf16 when eligible, 1 = fp32 VALU kernels always
 
 template <typename T>
 __device__ __forceinline__ void load_row64(const T* p, float (&v)[HD]) {
@@ -499,6 +510,9 @@ template <typename T>
 int launch_fwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t kv_stride, void* o, int64_t o_stride,
                float* lse, const int32_t* tt, int64_t B, int64_t H, int64_t Tq, int64_t M, int64_t n_per_media, int mask_mode,
                float scale, hipStream_t st) {
+    if (g_attn_variant == 0 && otter_xattn::eligible(sizeof(T) == 2 ? OTTER_BF16 : OTTER_F32, mask_mode, n_per_media, q_stride, kv_stride, q, k, v) &&
+        o_stride % 8 == 0 && (((uintptr_t)o & 15) == 0))
+        return otter_xattn::fwd(q, q_stride, k, v, kv_stride, o, o_stride, lse, tt, B, H, Tq, M, n_per_media, mask_mode, scale, st);
     const bool splitk = (Tq <= 64 && M > 256) || (B * H * cdiv64(Tq, 256) < 64 && M >= 256);
     if (splitk) {
         const int smem = (4 * 64 * 65 + 8 * 64) * 4;  // merge image (>= 4 * 2*KC_K*HD staging floats)
@@ -531,6 +545,17 @@ int launch_bwd(const void* q, int64_t q_stride, const void* k, const void* v, in
     const int64_t slab = Z * B * M * H * HD;
     float* part_k = delta + ((B * H * Tq + 63) / 64) * 64;
     float* part_v = part_k + slab;
+    if (g_attn_variant == 0 && otter_xattn::eligible(sizeof(T) == 2 ? OTTER_BF16 : OTTER_F32, mask_mode, n_per_media, q_stride, kv_stride, q, k, v) &&
+        o_stride % 8 == 0 && dq_stride % 8 == 0 && ((((uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq) & 15) == 0)) {
+        int rc = otter_xattn::bwd(q, q_stride, k, v, kv_stride, o, d_o, o_stride, lse, tt, dq, dq_stride, delta, part_k, part_v, B, H, Tq, M,
+                                  n_per_media, mask_mode, scale, st);
+        if (rc) return rc;
+        const int64_t chunks = B * M * (H * HD / 8);
+        hipLaunchKernelGGL((attn_bwd_dkv_reduce_kernel<T>), dim3((unsigned)cdiv64(chunks, 256)), dim3(256), 0, st, part_k, part_v,
+                           (T*)dk, (T*)dv, dkv_stride, B * M, (int)(H * HD), (int)Z);
+        OTTER_CHECK_LAUNCH("attn_bwd_dkv_reduce");
+        return OTTER_OK;
+    }
     const bool splitk = (Tq <= 64 && M > 256) || (B * H * cdiv64(Tq, 256) < 64 && M >= 256);
     if (splitk) {
         const int smem = (4 * 64 * 65 + 8 * 64) * 4;
@@ -580,6 +605,12 @@ int check_common(const void* q, const void* k, const void* v, int64_t q_stride, 
 }  // namespace
 
 extern "C" {
+
+int otter_attn_set_variant(int v) {
+    OTTER_REQUIRE(v == 0 || v == 1, "attn variant %d (0 = MFMA kernels for bf16, 1 = fp32 VALU kernels)", v);
+    g_attn_variant = v;
+    return OTTER_OK;
+}
 
 int otter_text_time(const uint8_t* media_locations, int32_t* text_time, int64_t B, int64_t T, int attend_previous, void* stream) {
     OTTER_REQUIRE(media_locations && text_time && B > 0 && T > 0, "text_time: bad args");

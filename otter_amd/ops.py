@@ -358,6 +358,11 @@ def add_rows_(dst2d, src2d, src_map: RowMap):
     return dst2d
 
 
+def set_attn_variant(v: int):
+    """0 = MFMA attention cores for bf16 (default), 1 = fp32 VALU kernels (A/B hook)."""
+    K.check(K.lib().otter_attn_set_variant(int(v)), "attn_set_variant")
+
+
 def set_flash_variant(v: int):
     """0 = default, 1 = register-staged tiles, 2 = LDS-DMA tiles (A/B hook of the decoder-host flash attention)."""
     K.check(K.lib().otter_flash_set_variant(int(v)), "flash_set_variant")

@@ -349,12 +349,24 @@ ATTN_CASES = [
     (2, 8, 64, 320, 1, 0),
     (1, 4, 40, 2112, 1, 0),
     (3, 8, 520, 64, 64, 1),
+    (2, 4, 200, 192, 64, 2),
+    (1, 2, 70, 96, 32, 1),
 ]
 
 
 @pytest.mark.parametrize("case", ATTN_CASES)
-@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("dt", ["f32", "bf16", "bf16-valu"])
 def test_attention_core(ops, case, dt):
+    """bf16 runs the MFMA kernels (attn_mfma.hip) where eligible, "bf16-valu" forces the fp32 VALU kernels on bf16 data."""
+    ops.set_attn_variant(1 if dt == "bf16-valu" else 0)
+    dt = "bf16" if dt == "bf16-valu" else dt
+    try:
+        _attention_core_case(ops, case, dt)
+    finally:
+        ops.set_attn_variant(0)
+
+
+def _attention_core_case(ops, case, dt):
     B, H, Tq, M, n, mode = case
     r = rng(sum(case))
     tdt = torch.float32 if dt == "f32" else torch.bfloat16
