@@ -72,13 +72,14 @@ int otter_add_layernorm_fwd(const void* x, int x_dtype, const void* delta, int d
                             int64_t D, float eps, void* stream);
 
 /* dx = LN'(dy) (+ dres if given, same dtype as dx).  dy is read through dy_map (same convention as the forward's
- * y_map).  dgamma/dbeta (fp32, [D]) are OVERWRITTEN (or accumulated when accumulate != 0).  ws: see
- * otter_layernorm_bwd_workspace_bytes.  gamma may be NULL (treated as ones); dbeta may be NULL. */
+ * y_map).  dx_bf16 (optional) receives a bf16 copy of dx in the same pass (the gradient of the bf16 branch output that was
+ * added to the fp32 residual stream).  dgamma/dbeta (fp32, [D]) are OVERWRITTEN (or accumulated when accumulate != 0).
+ * ws: see otter_layernorm_bwd_workspace_bytes.  gamma may be NULL (treated as ones); dbeta may be NULL. */
 int64_t otter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D);
 int otter_layernorm_bwd(const void* dy, int dy_dtype, otter_rowmap dy_map, const void* x, int x_dtype,
                         const void* gamma, int w_dtype, const float* mean, const float* rstd, const void* dres,
-                        void* dx, int dx_dtype, float* dgamma, float* dbeta, int accumulate, void* ws, int64_t rows,
-                        int64_t D, void* stream);
+                        void* dx, int dx_dtype, void* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* ws,
+                        int64_t rows, int64_t D, void* stream);
 
 /* out[c] (+)= sum_r src[map(r)][c]  (fp32 [D]).  Gradient of a broadcast embedding row: frame_embs /
  * media_time_embs (modeling_otter.py:224-229).  ws: otter_layernorm_bwd_workspace_bytes(rows, D). */

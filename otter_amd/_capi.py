@@ -66,7 +66,7 @@ SIGNATURES = {
     "otter_layernorm_fwd": (_int, [_vp, _int, _vp, _vp, _int, _vp, _int, RowMap, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "otter_add_layernorm_fwd": (_int, [_vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _i64, _i64, _f32, _vp]),
     "otter_layernorm_bwd_workspace_bytes": (_i64, [_i64, _i64]),
-    "otter_layernorm_bwd": (_int, [_vp, _int, RowMap, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _int, _vp,
+    "otter_layernorm_bwd": (_int, [_vp, _int, RowMap, _vp, _int, _vp, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _vp, _int, _vp,
                                    _i64, _i64, _vp]),
     "otter_colsum": (_int, [_vp, _int, RowMap, _vp, _int, _vp, _i64, _i64, _vp]),
     "otter_rmsnorm_fwd": (_int, [_vp, _int, _vp, _int, _vp, _vp, _i64, _i64, _f32, _vp]),

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const void* __restrict
                                                           const void* __restrict__ x, int xdt, const void* __restrict__ gamma,
                                                           int wdt, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const void* __restrict__ dres, void* __restrict__ dx, int dxdt,
-                                                          int64_t rows, int D) {
+                                                          bf16_t* __restrict__ dx2, int64_t rows, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void norm_bwd_dx_kernel(const void* __restrict
                 o[i] = t;
             }
             store8(dx, row * D + col, dxdt, o);
+            if (dx2) Vec8<bf16_t>::store(dx2 + row * D + col, o);  // bf16 copy for a bf16 consumer (no separate cast pass)
         }
     }
 }
@@ -264,14 +265,14 @@ int launch_fwd(const void* x, int xdt, const void* gamma, const void* beta, int 
 
 template <bool RMS>
 int launch_bwd(const void* dy, int dydt, otter_rowmap dymap, const void* x, int xdt, const void* gamma, int wdt,
-               const float* mean, const float* rstd, const void* dres, void* dx, int dxdt, float* dgamma, float* dbeta,
+               const float* mean, const float* rstd, const void* dres, void* dx, int dxdt, bf16_t* dx2, float* dgamma, float* dbeta,
                int accumulate, void* ws, int64_t rows, int64_t D, hipStream_t st) {
     OTTER_REQUIRE(dy && x && rstd && rows > 0, "norm_bwd: null pointer or empty shape");
     OTTER_REQUIRE(D % 8 == 0 && D <= 8192, "norm_bwd: D=%ld must be a multiple of 8 and <= 8192", (long)D);
     const int nch = pick_nch(D);
     if (dx) {
         dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
-#define L(N) hipLaunchKernelGGL((norm_bwd_dx_kernel<N, RMS>), grid, block, 0, st, dy, dydt, dymap, x, xdt, gamma, wdt, mean, rstd, dres, dx, dxdt, rows, (int)D)
+#define L(N) hipLaunchKernelGGL((norm_bwd_dx_kernel<N, RMS>), grid, block, 0, st, dy, dydt, dymap, x, xdt, gamma, wdt, mean, rstd, dres, dx, dxdt, dx2, rows, (int)D)
         switch (nch) {
             case 1: L(1); break;
             case 2: L(2); break;
@@ -320,10 +321,11 @@ int64_t otter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (i
 
 int otter_layernorm_bwd(const void* dy, int dy_dtype, otter_rowmap dy_map, const void* x, int x_dtype, const void* gamma,
                         int w_dtype, const float* mean, const float* rstd, const void* dres, void* dx, int dx_dtype,
-                        float* dgamma, float* dbeta, int accumulate, void* ws, int64_t rows, int64_t D, void* stream) {
+                        void* dx_bf16, float* dgamma, float* dbeta, int accumulate, void* ws, int64_t rows, int64_t D, void* stream) {
     OTTER_REQUIRE(mean, "layernorm_bwd: mean is required");
-    return launch_bwd<false>(dy, dy_dtype, dy_map, x, x_dtype, gamma, w_dtype, mean, rstd, dres, dx, dx_dtype, dgamma, dbeta,
-                             accumulate, ws, rows, D, (hipStream_t)stream);
+    OTTER_REQUIRE(!dx_bf16 || dx, "layernorm_bwd: dx_bf16 without dx");
+    return launch_bwd<false>(dy, dy_dtype, dy_map, x, x_dtype, gamma, w_dtype, mean, rstd, dres, dx, dx_dtype, (bf16_t*)dx_bf16, dgamma,
+                             dbeta, accumulate, ws, rows, D, (hipStream_t)stream);
 }
 
 int otter_colsum(const void* src, int src_dtype, otter_rowmap src_map, float* out, int accumulate, void* ws, int64_t rows,
@@ -351,7 +353,7 @@ int otter_rmsnorm_fwd(const void* x, int x_dtype, const void* w, int w_dtype, vo
 int otter_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd, void* dx,
                       float* dw, int accumulate, void* ws, int64_t rows, int64_t D, void* stream) {
     otter_rowmap id = {0, 0, 0};
-    return launch_bwd<true>(dy, x_dtype, id, x, x_dtype, w, w_dtype, nullptr, rstd, nullptr, dx, x_dtype, dw, nullptr,
+    return launch_bwd<true>(dy, x_dtype, id, x, x_dtype, w, w_dtype, nullptr, rstd, nullptr, dx, x_dtype, nullptr, dw, nullptr,
                             accumulate, ws, rows, D, (hipStream_t)stream);
 }
 

@@ -162,9 +162,13 @@ class AddLayerNormFn(torch.autograd.Function):
         need_dw = weight is not None and weight.requires_grad
         D = ctx.shp[-1]
         dres = d_xsum.reshape(-1, D).contiguous() if d_xsum is not None else None
+        # the gradient of the (bf16) branch output is the same tensor in its dtype: written by the same pass
+        fused = ctx.needs_input_grad[1] and ctx.ddtype == torch.bfloat16 and xsum.dtype != torch.bfloat16
+        ddelta = torch.empty(xsum.shape, dtype=torch.bfloat16, device=xsum.device) if fused else None
         dx, dg, db = ops.layernorm_bwd(dy.reshape(-1, D).contiguous(), xsum, weight.detach() if weight is not None else None, mean,
-                                       rstd, xsum.dtype, dres=dres, need_dw=need_dw, need_dbeta=ctx.has_bias)
-        ddelta = ops.cast(dx, ctx.ddtype) if ctx.needs_input_grad[1] else None
+                                       rstd, xsum.dtype, dres=dres, need_dw=need_dw, need_dbeta=ctx.has_bias, dx_bf16=ddelta)
+        if not fused:
+            ddelta = ops.cast(dx, ctx.ddtype) if ctx.needs_input_grad[1] else None
         return (dx.view(ctx.shp), ddelta.view(ctx.shp) if ddelta is not None else None,
                 dg.to(weight.dtype) if dg is not None else None, db.to(weight.dtype) if (db is not None and ctx.has_bias) else None,
                 None, None)

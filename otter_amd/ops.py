@@ -91,14 +91,17 @@ def add_layernorm_fwd(x2d, delta2d, gamma, beta, out_dtype, eps=1e-5, need_stats
 
 
 def layernorm_bwd(dy, x2d, gamma, mean, rstd, dx_dtype, dres=None, dymap: Optional[RowMap] = None, need_dw=True,
-                  need_dbeta=True, need_dx=True):
-    """Returns (dx, dgamma, dbeta) -- dgamma/dbeta fp32."""
+                  need_dbeta=True, need_dx=True, dx_bf16=None):
+    """Returns (dx, dgamma, dbeta) -- dgamma/dbeta fp32.  dx_bf16: optional preallocated bf16 [rows, D] tensor that
+    receives a bf16 copy of dx in the same pass."""
     K.require_cuda(dy, x2d)
     rows, D = x2d.shape
     dev = x2d.device
     dx = torch.empty((rows, D), dtype=dx_dtype, device=dev) if need_dx else None
     if dres is not None and dres.dtype != dx_dtype:
         raise K.OtterHipError("layernorm_bwd: dres must have the dx dtype")
+    if dx_bf16 is not None and (dx_bf16.dtype != torch.bfloat16 or not dx_bf16.is_contiguous() or tuple(dx_bf16.shape) != (rows, D)):
+        raise K.OtterHipError("layernorm_bwd: dx_bf16 must be a contiguous bf16 [rows, D] tensor")
     dg = torch.empty(D, dtype=torch.float32, device=dev) if need_dw else None
     db = torch.empty(D, dtype=torch.float32, device=dev) if (need_dw and need_dbeta) else None
     ws = None
@@ -106,8 +109,8 @@ def layernorm_bwd(dy, x2d, gamma, mean, rstd, dx_dtype, dres=None, dymap: Option
         ws = _ws.get(K.lib().otter_layernorm_bwd_workspace_bytes(rows, D), dev)
     wdt = K.dt(gamma) if gamma is not None else F32
     K.check(K.lib().otter_layernorm_bwd(dy.data_ptr(), K.dt(dy), dymap or _IDENT, x2d.data_ptr(), K.dt(x2d), K.ptr(gamma), wdt,
-                                        mean.data_ptr(), rstd.data_ptr(), K.ptr(dres), K.ptr(dx), K.dt_of(dx_dtype), K.ptr(dg),
-                                        K.ptr(db), 0, K.ptr(ws), rows, D, K.stream()), "layernorm_bwd")
+                                        mean.data_ptr(), rstd.data_ptr(), K.ptr(dres), K.ptr(dx), K.dt_of(dx_dtype), K.ptr(dx_bf16),
+                                        K.ptr(dg), K.ptr(db), 0, K.ptr(ws), rows, D, K.stream()), "layernorm_bwd")
     return dx, dg, db
 
 

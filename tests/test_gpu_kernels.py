@@ -118,6 +118,13 @@ def test_add_layernorm_fused(ops):
     assert np.array_equal(host(xsum), x + delta)  # fp32 add of the same operands: bit-exact
     y_ref, _ = O.layer_norm_fwd(x + delta, w, None)
     assert relmax(host(y), y_ref) < 1e-2 and y.dtype == torch.bfloat16
+    # backward with the fused bf16 copy of dx (the branch gradient): identical to casting dx afterwards
+    dy = to_dev(bf16_round(r.standard_normal((rows, D)).astype(np.float32)), torch.bfloat16)
+    dres = to_dev(r.standard_normal((rows, D)).astype(np.float32))
+    dx2 = torch.empty(rows, D, dtype=torch.bfloat16, device=DEV)
+    dx, _, _ = ops.layernorm_bwd(dy, xsum, to_dev(w), mean, rstd, torch.float32, dres=dres, need_dw=False, dx_bf16=dx2)
+    dx_plain, _, _ = ops.layernorm_bwd(dy, xsum, to_dev(w), mean, rstd, torch.float32, dres=dres, need_dw=False)
+    assert torch.equal(dx, dx_plain) and torch.equal(dx2, dx.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
