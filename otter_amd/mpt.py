@@ -92,12 +92,51 @@ class _Norm(nn.LayerNorm):
         return OF.add_layer_norm(x, delta, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
 
 
+class _FrozenLinearFn(torch.autograd.Function):
+    """y = x W^T whose input gradient is computed against a stored transposed copy of the (frozen) weight."""
+
+    @staticmethod
+    def forward(ctx, x, w, wt):
+        ctx.save_for_backward(wt)
+        return F.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (wt,) = ctx.saved_tensors
+        return F.linear(dy, wt), None, None
+
+
+class FrozenAwareLinear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict keys).  When the weight is frozen -- as the whole decoder is in the Otter
+    recipe -- the only backward product is dx = dy W, which hipBLASLt runs 13-17 % faster in its "x W^T" form against a
+    K-contiguous operand (tools/lm_gemm_layouts.py: 330 -> 270, 108 -> 95, 412 -> 355, 421 -> 361 us on the four decoder
+    shapes at C2).  The weight never changes, so a transposed copy in the compute dtype is built once (13 GB for MPT-7B
+    out of 288 GB of HBM) and the dgrad is issued as F.linear(dy, W^T)."""
+
+    def _copies(self, cd):
+        w = self.weight
+        key = (w._version, w.data_ptr(), cd)
+        if getattr(self, "_fz_key", None) != key:
+            wc = w.detach() if w.dtype == cd else w.detach().to(cd)
+            self._fz_w, self._fz_wt, self._fz_key = wc, wc.t().contiguous(), key
+        return self._fz_w, self._fz_wt
+
+    def forward(self, x):
+        w = self.weight
+        if (w.requires_grad or self.bias is not None or not x.is_cuda or not torch.is_grad_enabled() or not x.requires_grad
+                or os.environ.get("OTTER_NO_FROZEN_WT") == "1"):
+            return F.linear(x, w, self.bias)
+        cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        wc, wt = self._copies(cd)
+        return _FrozenLinearFn.apply(x if x.dtype == cd else x.to(cd), wc, wt)
+
+
 class MPTMLP(nn.Module):
     def __init__(self, d_model, expansion_ratio, bias):
         super().__init__()
-        self.up_proj = nn.Linear(d_model, expansion_ratio * d_model, bias=bias)
+        self.up_proj = FrozenAwareLinear(d_model, expansion_ratio * d_model, bias=bias)
         self.act = nn.GELU()
-        self.down_proj = nn.Linear(expansion_ratio * d_model, d_model, bias=bias)
+        self.down_proj = FrozenAwareLinear(expansion_ratio * d_model, d_model, bias=bias)
 
     def forward(self, x):
         return self.down_proj(self.act(self.up_proj(x)))
@@ -108,8 +147,8 @@ class MultiheadAttention(nn.Module):
         super().__init__()
         self.d_model, self.n_heads = d_model, n_heads
         self.softmax_scale = 1.0 / math.sqrt(d_model / n_heads)
-        self.Wqkv = nn.Linear(d_model, 3 * d_model, bias=bias)
-        self.out_proj = nn.Linear(d_model, d_model, bias=bias)
+        self.Wqkv = FrozenAwareLinear(d_model, 3 * d_model, bias=bias)
+        self.out_proj = FrozenAwareLinear(d_model, d_model, bias=bias)
 
     def forward(self, x, past_key_value=None, attn_bias=None, is_causal=True, flash=None):
         B, S, D = x.shape
