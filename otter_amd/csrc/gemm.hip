@@ -37,6 +37,7 @@ struct GemmArgs {
     float* partial;
     int gm, gn;
     int dbg;  // diagnostics only (otter_gemm_set_debug): bit0 = skip K-loop global loads, bit1 = skip MFMAs
+    int wide;  // bf16 output and every tensor the fused tail touches allows 8-element accesses (N, ldc, ldc2, ldr, ldaux % 8 == 0)
 };
 
 __device__ __forceinline__ void load4(const void* p, int64_t idx, int dt, float (&v)[4]) {
@@ -126,6 +127,86 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
     return part;
 }
 
+// ---- 8 consecutive output columns per lane: 16-byte bf16 (2 x 16-byte f32) accesses, half as many store instructions ----
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ void load8w(const void* p, int64_t idx, int dt, float (&v)[8]) {
+    if (dt == OTTER_BF16) {
+        const uint4 r = *reinterpret_cast<const uint4*>((const bf16_t*)p + idx);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>((const float*)p + idx), b = *reinterpret_cast<const float4*>((const float*)p + idx + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+__device__ __forceinline__ void store8w(void* p, int64_t idx, int dt, const float (&v)[8]) {
+    if (dt == OTTER_BF16) {
+        u32x4_t r;
+        r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
+        __builtin_nontemporal_store(r, reinterpret_cast<u32x4_t*>((bf16_t*)p + idx));
+    } else {
+        f32x4_t a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        __builtin_nontemporal_store(a, reinterpret_cast<f32x4_t*>((float*)p + idx));
+        __builtin_nontemporal_store(b, reinterpret_cast<f32x4_t*>((float*)p + idx + 4));
+    }
+}
+template <int EPI>
+__device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m, int64_t n, float (&v)[8]) {
+    float part = 0.f;
+    float o[8];
+    switch (EPI) {
+        case OTTER_EPI_STORE: {
+            if (g.accumulate) {
+                float c[8];
+                load8w(g.C, m * g.ldc + n, g.cdt, c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = c[i] + s * v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = s * v[i];
+            }
+            break;
+        }
+        case OTTER_EPI_GELU: {
+            if (g.C2) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float cdf, pdf;
+                gelu_cdf_pdf(v[i], cdf, pdf);
+                o[i] = v[i] * cdf;
+            }
+            break;
+        }
+        case OTTER_EPI_SCALE_RES: {
+            float r[8];
+            load8w(g.R, m * g.ldr + n, g.rdt, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = v[i] * s + r[i];
+            break;
+        }
+        default: {  // OTTER_EPI_GATE_BWD
+            float a[8];
+            load8w(g.aux, m * g.ldaux + n, g.auxdt, a);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (g.aux_gelu) {
+                    float cdf, pdf;
+                    gelu_cdf_pdf(a[i], cdf, pdf);
+                    part += v[i] * (a[i] * cdf);
+                    o[i] = s * v[i] * (cdf + a[i] * pdf);
+                } else {
+                    part += v[i] * a[i];
+                    o[i] = s * v[i];
+                }
+            }
+            break;
+        }
+    }
+    store8w(g.C, m * g.ldc + n, g.cdt, o);
+    return part;
+}
+
 // Epilogue: a wave parks one 32-row stripe of its sub-tile (two 32x32 accumulator blocks side by side = 32 rows x 64
 // columns) in wave-private LDS as fp32, then reads it back row-major: lane l handles row (l>>4) + 4*it, columns
 // 4*(l&15)..+3, so 16 lanes cover one full 128-B (bf16) / 256-B (f32) run of an output row and every global access of
@@ -148,6 +229,23 @@ template <int EPI>
 __device__ __forceinline__ float epilogue_stripe(const GemmArgs& g, float s, const float* __restrict__ blk, int64_t m_base,
                                                  int64_t n_base, int lane) {
     float part = 0.f;
+    if (g.wide && !((OTTER_DIAG & 4) || (g.dbg & 16))) {
+        // lane l: row (l>>3) + 8*it, columns 8*(l&7)..+7 -- 8 lanes cover the 128-B (bf16) run of an output row with one
+        // 16-byte access each: half the store / load instructions and loop trips of the 4-wide form below
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int r = (lane >> 3) + 8 * it;
+            const int c = (lane & 7) * 8;
+            const int64_t m = m_base + r, n = n_base + c;
+            if (m < g.M && n < g.N) {
+                const float4 t0 = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
+                const float4 t1 = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c + 4);
+                float v[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                part += epilogue8<EPI>(g, s, m, n, v);
+            }
+        }
+        return part;
+    }
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const int r = (lane >> 4) + 4 * it;
@@ -1280,6 +1378,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
 int g_debug = 0;
+int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
 enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
@@ -1426,7 +1525,8 @@ int otter_gemm_set_variant(int variant) {
 }
 
 int otter_gemm_set_debug(int flags) {
-    g_debug = flags;
+    g_debug = flags & 255;
+    g_narrow_epilogue = (flags & 256) ? 1 : 0;
     return OTTER_OK;
 }
 
@@ -1476,6 +1576,10 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
     int bm, bn;
     cfg_tiles(cfg, bm, bn);
     g.dbg = g_debug;
+    // (fp32 outputs stay on the 4-wide tail: there a lane's 4 columns are already a 16-byte store and 16 lanes cover a
+    //  whole 256-byte row run; the 8-wide form would split every row into interleaved 16-byte halves: measured +15 %)
+    g.wide = (c_dtype == OTTER_BF16 && N % 8 == 0 && ldc % 8 == 0 && (!g.C2 || g.ldc2 % 8 == 0) && (g.kind != OTTER_EPI_SCALE_RES || g.ldr % 8 == 0) &&
+              (g.kind != OTTER_EPI_GATE_BWD || g.ldaux % 8 == 0) && !g_narrow_epilogue) ? 1 : 0;
     g.gm = (int)cdiv64(M, bm);
     g.gn = (int)cdiv64(N, bn);
     const dim3 grid((unsigned)(g.gm * g.gn));

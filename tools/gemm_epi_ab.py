@@ -34,5 +34,12 @@ cases = {
     "gate_bwd_gelu": lambda: ops.gemm_nt(A, B, out=C16, kind=EPI_GATE_BWD, gate=gate, aux=aux, aux_gelu=True, partial=part),
     "scale_res_f32": lambda: ops.gemm_nt(A2, B2, out=Y, kind=EPI_SCALE_RES, gate=gate, R=R),
 }
-res = {k: round(statistics.median(bench(f) for _ in range(3)), 1) for k, f in cases.items()}
-print(json.dumps({"lib": os.path.basename(os.environ.get("OTTER_LIB_PATH") or "libotter_hip.so"), **res}))
+from otter_amd import _capi
+res = {}
+for rnd in range(3):   # interleaved: wide (16-byte) fused tail vs the 4-wide one (debug bit 256)
+    for flag, tag in ((0, "wide"), (256, "narrow")):
+        _capi.lib().otter_gemm_set_debug(flag)
+        for k, f in cases.items():
+            res.setdefault(k + ":" + tag, []).append(bench(f))
+_capi.lib().otter_gemm_set_debug(0)
+print(json.dumps({k: round(statistics.median(v), 1) for k, v in res.items()}))
