@@ -1,3 +1,4 @@
+// ds_read_b64_tr_b16 semantics probe (build: hipcc --offload-arch=gfx950 -O2 tr_probe.hip -o tr_probe.bin; prints which LDS element each lane receives)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef short s4 __attribute__((ext_vector_type(4)));
