@@ -108,8 +108,12 @@ class FusedAdamW:
         # parameters that have a bf16 copy in the GEMM operand cache get it refreshed by the update kernel itself
         sh = [shadows.stale_w(p, torch.bfloat16) if self.refresh_shadows else None for p, _ in live]
         t["meta"]["shadow"] = [0 if x is None else x.data_ptr() for x in sh]
+        if t.get("copied") is not None:
+            t["copied"].synchronize()   # the previous step's upload has left the pinned staging buffer
         t["hmeta"].numpy()[:] = t["meta"].view(np.uint8)
         t["dmeta"].copy_(t["hmeta"], non_blocking=True)
+        t["copied"] = torch.cuda.Event()
+        t["copied"].record()
         self._step += 1
         b1, b2 = g0["betas"]
         lib, st = K.lib(), K.stream()
