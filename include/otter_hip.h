@@ -235,6 +235,18 @@ int otter_add_frame_embs(void* x, int x_dtype, const float* emb, int64_t outer, 
 int otter_add_rows(void* dst, const void* src, otter_rowmap src_map, int64_t rows, int64_t D, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Token cross-entropy of the decoder host on bf16 logits: F.cross_entropy(logits.view(-1, V), labels) with
+ * ignore_index = -100 and mean reduction     /root/reference/src/otter_ai/models/mpt/modeling_mpt.py:428-435
+ * (the caller rolls the labels).  fwd: lse[r], nll[r] (0 for ignored rows) from one read of the logits; the mean
+ * is sum(nll) / max(n_valid, 1).  bwd: dlogits (bf16) = (softmax - onehot) * (*dloss) / max(*n_valid, 1), zero rows for
+ * ignored labels; dloss and n_valid are device scalars (no host synchronisation).
+ * ------------------------------------------------------------------------------------------------------- */
+int otter_cross_entropy_fwd(const void* logits, int64_t ld, const int64_t* labels, float* lse, float* nll, int64_t rows, int64_t V,
+                            void* stream);
+int otter_cross_entropy_bwd(const void* logits, int64_t ld, const int64_t* labels, const float* lse, const float* dloss,
+                            const float* n_valid, void* dlogits, int64_t ldd, int64_t rows, int64_t V, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Optimizer step of the recipe: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by
  * torch.optim.AdamW.step()          /root/reference/pipeline/train/instruction_following.py:246-251
  * as two sweeps: otter_grad_sumsq (+ otter_clip_coef -> {norm, coefficient} on the device) and otter_adamw_step, which

@@ -91,6 +91,8 @@ SIGNATURES = {
     "otter_flash_attn_fwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_flash_attn_bwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_flash_set_variant": (_int, [_int]),
+    "otter_cross_entropy_fwd": (_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp]),
+    "otter_cross_entropy_bwd": (_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "otter_adamw_chunk": (_int, []),
     "otter_grad_sumsq": (_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "otter_clip_coef": (_int, [_vp, _i64, _f32, _vp, _vp]),

@@ -316,6 +316,43 @@ def flash_self_attention(qkv, n_heads, slopes, key_valid, scale, causal=True):
     return FlashSelfAttentionFn.apply(qkv, n_heads, slopes, key_valid, scale, causal)
 
 
+class CrossEntropyBf16Fn(torch.autograd.Function):
+    """Mean token cross-entropy (ignore_index -100) on bf16 logits [rows, V] without materialising an fp32 copy
+    (mpt/modeling_mpt.py:428-435 once the labels are rolled).  fp32 arithmetic on the bf16 values = what
+    F.cross_entropy(logits.float(), labels) computes; the gradient is produced directly in bf16."""
+
+    @staticmethod
+    def forward(ctx, logits2d, labels):
+        K_ = ops.K
+        K_.require_cuda(logits2d, labels)
+        rows, V = logits2d.shape
+        if logits2d.dtype != torch.bfloat16 or logits2d.stride(1) != 1 or labels.dtype != torch.int64 or not labels.is_contiguous():
+            raise K_.OtterHipError("cross_entropy: bf16 [rows, V] logits with unit column stride and contiguous int64 labels")
+        lse = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+        nll = torch.empty(rows, dtype=torch.float32, device=logits2d.device)
+        K_.check(K_.lib().otter_cross_entropy_fwd(logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), lse.data_ptr(), nll.data_ptr(),
+                                                  rows, V, K_.stream()), "cross_entropy_fwd")
+        n_valid = (labels >= 0).sum().to(torch.float32)
+        ctx.save_for_backward(logits2d, labels, lse, n_valid)
+        return nll.sum() / n_valid.clamp(min=1.0)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        K_ = ops.K
+        logits2d, labels, lse, n_valid = ctx.saved_tensors
+        rows, V = logits2d.shape
+        dlogits = torch.empty((rows, V), dtype=torch.bfloat16, device=logits2d.device)
+        dl = dloss.to(torch.float32).contiguous()
+        K_.check(K_.lib().otter_cross_entropy_bwd(logits2d.data_ptr(), logits2d.stride(0), labels.data_ptr(), lse.data_ptr(), dl.data_ptr(),
+                                                  n_valid.data_ptr(), dlogits.data_ptr(), dlogits.stride(0), rows, V, K_.stream()),
+                 "cross_entropy_bwd")
+        return dlogits, None
+
+
+def cross_entropy_bf16(logits2d, labels):
+    return CrossEntropyBf16Fn.apply(logits2d, labels)
+
+
 def masked_cross_attention(x, media, tt, mask_mode, heads, eps, norm_w, norm_b, Wq, Wkv, Wo):
     """OtterMaskedCrossAttention.forward (modeling_otter.py:262-340) used stand-alone: returns to_out(attn) in the compute
     dtype (bf16 under autocast, like the reference)."""
