@@ -14,6 +14,7 @@ lib = _capi.lib()
 lib.otter_flash_set_stamps.argtypes = [ctypes.c_void_p]
 assert lib.otter_flash_set_stamps(st.data_ptr()) == 0
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+ops.set_flash_variant(1)   # the stamps live in the register-staged first version of the forward
 for _ in range(3):
     ops.flash_attn_fwd(q, k, v, sl, None, 1 / math.sqrt(128), True)
 torch.cuda.synchronize()
