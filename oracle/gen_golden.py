@@ -8,7 +8,9 @@ What pins what:
   * otter_tiny runs a complete OtterForConditionalGeneration (MPT text config, 1-layer CLIP) incl. loss.backward()
     and a hand-written greedy loop over model.lang_encoder (HF generate() of the pinned transformers==4.35.1 is not
     importable here -- SURVEY.md section 8c) in both decode modes;
-  * llama_* cases use transformers' LlamaRMSNorm / apply_rotary_pos_emb (third-party arithmetic for config C4).
+  * llama_* cases use transformers' LlamaRMSNorm / apply_rotary_pos_emb (third-party arithmetic for config C4);
+  * mpt_attn runs src/otter_ai/models/mpt/attention.py::scaled_multihead_dot_product_attention + build_alibi_bias
+    (causal / ALiBi / key padding) -- the checker of the decoder-host flash kernels.
 Weights and inputs are pure functions of (seed, name, shape) -- see oracle/synth.py -- so fixtures hold outputs only.
 """
 from __future__ import annotations
@@ -297,9 +299,44 @@ def case_llama(name="llama_ops", seed=11):
     return {"seed": seed, "D": D, "S": S, "H": H, "d": d}
 
 
+def case_mpt_attn(name="mpt_attn", seed=17):
+    """The decoder host's attention core exactly as the reference calls it (mpt/attention.py:22-84 with the ALiBi bias of
+    :447-464, key padding and the causal mask): pins oracle.mpt_attention_core, the checker of the HIP flash kernels."""
+    import_reference()
+    from src.otter_ai.models.mpt.attention import build_alibi_bias, scaled_multihead_dot_product_attention  # type: ignore
+
+    B, H, S, d = 2, 4, 40, 32
+    lens = [40, 29]
+    res = {}
+    for tag, causal, alibi, pad in (("a", True, True, True), ("b", False, False, False), ("c", True, True, False)):
+        q, k, v = (torch.from_numpy(synth.tensor(seed, f"attn.{tag}.{n}", (B, S, H * d))).requires_grad_(True) for n in "qkv")
+        bias = build_alibi_bias(H, S, full=False, alibi_bias_max=8) if alibi else None
+        kpm = None
+        if pad:
+            kpm = torch.zeros(B, S, dtype=torch.bool)
+            for b, n in enumerate(lens):
+                kpm[b, :n] = True
+        out, _, _ = scaled_multihead_dot_product_attention(q, k, v, H, softmax_scale=1.0 / (d ** 0.5), attn_bias=bias,
+                                                            key_padding_mask=kpm, is_causal=causal)
+        R = torch.from_numpy(synth.tensor(seed, f"attn.{tag}.R", (B, S, H * d)))
+        (out * R).sum().backward()
+        res.update({f"{tag}_out": out.detach().numpy(), f"{tag}_dq": q.grad.numpy(), f"{tag}_dk": k.grad.numpy(), f"{tag}_dv": v.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **res)
+    return {"seed": seed, "B": B, "H": H, "S": S, "d": d, "lens": lens,
+            "cases": {"a": [True, True, True], "b": [False, False, False], "c": [True, True, False]}}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "mpt_attn":   # add / refresh just this case
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["mpt_attn"] = case_mpt_attn()
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        print("wrote mpt_attn")
+        return
     mo = import_reference()
     meta = {}
     meta["perceiver_image"] = case_perceiver(mo, "perceiver_image", 1, 128, 2, 16, (2, 2, 1, 10, 128))
@@ -312,6 +349,7 @@ def main():
     meta["otter_tiny"] = case_otter_tiny(mo)
     meta["otter_tiny_llama"] = case_otter_tiny_llama(mo)
     meta["llama_ops"] = case_llama()
+    meta["mpt_attn"] = case_mpt_attn()
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", sorted(os.listdir(OUT)))

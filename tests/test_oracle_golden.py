@@ -102,3 +102,27 @@ def test_llama_ops():
     assert G.rel_err(O.rope_fwd(k, cos, sin).transpose(0, 2, 1, 3), gold["rope_k"]) < 1e-5
     R = synth.tensor(s, "rope.R", (2, m["H"], m["S"], m["d"])).transpose(0, 2, 1, 3)
     assert G.rel_err(O.rope_bwd(R, cos, sin).transpose(0, 2, 1, 3), gold["rope_dq"]) < 1e-5
+
+
+def test_mpt_attention_core():
+    """oracle.mpt_attention_core (the checker of the HIP flash kernels) against the reference's own
+    scaled_multihead_dot_product_attention + build_alibi_bias (mpt/attention.py:22-84, 447-464): causal + ALiBi + key
+    padding, plain, and causal + ALiBi."""
+    m = G.meta()["mpt_attn"]
+    gold = G.load("mpt_attn")
+    s, B, H, S, d = m["seed"], m["B"], m["H"], m["S"], m["d"]
+    slopes = O.alibi_slopes(H, 8)
+    for tag, (causal, alibi, pad) in m["cases"].items():
+        q, k, v, R = (synth.tensor(s, f"attn.{tag}.{n}", (B, S, H * d)) for n in ("q", "k", "v", "R"))
+        kpm = None
+        if pad:
+            kpm = np.zeros((B, S), bool)
+            for b, n in enumerate(m["lens"]):
+                kpm[b, :n] = True
+        ctx, (dq, dk, dv) = O.mpt_attention_core(O._split_heads(q, H), O._split_heads(k, H), O._split_heads(v, H),
+                                                 np.float32(1.0 / np.sqrt(d)), slopes if alibi else None, kpm, causal,
+                                                 O._split_heads(R, H))
+        assert G.rel_err(O._merge_heads(ctx), gold[f"{tag}_out"]) < 2e-5
+        assert G.rel_err(O._merge_heads(dq), gold[f"{tag}_dq"]) < 1e-4
+        assert G.rel_err(O._merge_heads(dk), gold[f"{tag}_dk"]) < 1e-4
+        assert G.rel_err(O._merge_heads(dv), gold[f"{tag}_dv"]) < 1e-4
