@@ -252,7 +252,9 @@ int otter_cross_entropy_bwd(const void* logits, int64_t ld, const int64_t* label
  * as two sweeps: otter_grad_sumsq (+ otter_clip_coef -> {norm, coefficient} on the device) and otter_adamw_step, which
  * multiplies the gradients by *grad_scale on the fly (the scaled gradients are NOT written back), follows torch's
  * fused AdamW arithmetic (decoupled weight decay, lerp first moment, bias corrections passed in) and optionally
- * refreshes a bf16 copy of each parameter.  `tensors` is a DEVICE array; block i of the launch owns elements
+ * refreshes a bf16 copy of each parameter.  torch.optim.AdamW keeps one `step` per parameter and one lr per param
+ * group: a table row may carry its own lr / bias corrections (bias_correction1 != 0), which then override the
+ * launch-wide arguments for that tensor.  `tensors` is a DEVICE array; block i of the launch owns elements
  * [blk_chunk[i] * otter_adamw_chunk(), ...) of tensors[blk_tensor[i]].
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct otter_adamw_tensor {
@@ -260,8 +262,10 @@ typedef struct otter_adamw_tensor {
     uint16_t* shadow;      /* bf16 copy of p, or NULL */
     int64_t numel;
     float weight_decay;
-    int32_t reserved;
-} otter_adamw_tensor;
+    float lr;                      /* used when bias_correction1 != 0 (per-group learning rate) */
+    float bias_correction1;        /* 1 - beta1^step of THIS tensor; 0 = use the launch-wide lr / bias corrections */
+    float bias_correction2_sqrt;   /* sqrt(1 - beta2^step) of this tensor */
+} otter_adamw_tensor;              /* 64 bytes */
 
 int otter_adamw_chunk(void);
 int otter_grad_sumsq(const otter_adamw_tensor* tensors, const int32_t* blk_tensor, const int32_t* blk_chunk, int64_t nblocks,

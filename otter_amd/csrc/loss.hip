@@ -2,7 +2,8 @@
 // F.cross_entropy(logits.view(-1, V), labels) with ignore_index -100, mean over the valid rows).
 // torch runs this as: bf16 -> fp32 copy of the [4096, 50432] logits, log_softmax, nll, and three more fp32 passes in the
 // backward.  Here: one read of the bf16 logits for (lse, nll) and, in the backward, one read + one bf16 write for
-// dlogits = (softmax - onehot) * dloss / n_valid -- rows with label -100 are skipped (zero gradient row).
+// dlogits = (softmax - onehot) * dloss / n_valid -- rows with label -100 are skipped (zero gradient row); a label >= V
+// gives a NaN loss (never an out-of-bounds read).
 // fp32 arithmetic on the bf16 values, i.e. what `logits.float()` feeds torch.
 #include "common.h"
 
@@ -39,8 +40,13 @@ __global__ __launch_bounds__(NT) void ce_fwd_kernel(const bf16_t* __restrict__ l
     __shared__ float red[2 * NT / 64];
     const int64_t row = blockIdx.x;
     const int64_t lab = labels[row];
-    if (lab < 0) {  // ignore_index: no loss, no gradient
+    if (lab < 0) {  // ignore_index (any negative label): no loss, no gradient
         if (threadIdx.x == 0) { lse[row] = 0.f; nll[row] = 0.f; }
+        return;
+    }
+    if (lab >= V) {  // out-of-range label (tokenizer / vocabulary-padding mismatch): F.cross_entropy device-asserts here; we
+                     // never read x[lab] and poison the loss instead (NaN), the backward zero-fills the row
+        if (threadIdx.x == 0) { lse[row] = 0.f; nll[row] = __builtin_nanf(""); }
         return;
     }
     const bf16_t* x = logits + row * ld;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const bf16_t* __restrict__ l
     const bf16_t* x = logits + row * ld;
     bf16_t* d = dlogits + row * ldd;
     const int nch = V >> 3;
-    if (lab < 0) {
+    if (lab < 0 || lab >= V) {
         for (int c = threadIdx.x; c < nch; c += NT) *reinterpret_cast<uint4*>(d + 8 * c) = make_uint4(0, 0, 0, 0);
         for (int i = (nch << 3) + threadIdx.x; i < V; i += NT) d[i] = 0;
         return;

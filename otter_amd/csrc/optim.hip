@@ -63,6 +63,13 @@ __global__ __launch_bounds__(1024) void clip_coef_kernel(const float* __restrict
 
 struct Hyper { float lr, beta1, beta2, eps, bc1, bc2_sqrt; };
 
+// per-tensor overrides (torch keeps one `step` per parameter and one lr per param group): a table row with
+// bias_correction1 != 0 carries its own lr and bias corrections, otherwise the launch-wide values apply
+__device__ __forceinline__ Hyper hyper_of(const otter_adamw_tensor& t, Hyper h) {
+    if (t.bias_correction1 != 0.f) { h.lr = t.lr; h.bc1 = t.bias_correction1; h.bc2_sqrt = t.bias_correction2_sqrt; }
+    return h;
+}
+
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, float wd, const Hyper& h) {
     p -= h.lr * wd * p;
     m = m + (1.0f - h.beta1) * (g - m);                         // lerp(exp_avg, grad, 1 - beta1)
@@ -73,8 +80,9 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
 }
 
 __global__ __launch_bounds__(NT) void adamw_kernel(const otter_adamw_tensor* __restrict__ tensors, const int32_t* __restrict__ blk_tensor,
-                                                   const int32_t* __restrict__ blk_chunk, Hyper h, const float* __restrict__ grad_scale) {
+                                                   const int32_t* __restrict__ blk_chunk, Hyper h0, const float* __restrict__ grad_scale) {
     const otter_adamw_tensor t = tensors[blk_tensor[blockIdx.x]];
+    const Hyper h = hyper_of(t, h0);
     const int64_t beg = (int64_t)blk_chunk[blockIdx.x] * CHUNK;
     const int64_t end = beg + CHUNK < t.numel ? beg + CHUNK : t.numel;
     const float gs = grad_scale ? *grad_scale : 1.0f;

@@ -34,7 +34,7 @@ class _Bucket:
             off += (p.numel() + al - 1) // al * al
         self.flat = torch.zeros(off, dtype=dtype, device=device)   # padding stays zero (zeros reduce to zeros)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
-        self.pending = len(params)
+        self.ready = set()   # id(param) whose gradient of the CURRENT backward pass is in its view
         self.work = None
 
 
@@ -77,6 +77,11 @@ class GradReducer:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         from . import functional as _F
 
+        # one live reducer per parameter set: an older one over any of these parameters would keep its hooks and rebind
+        # p.grad to ITS buckets -- detach it (close() removes its hooks) instead of double-counting
+        old = _F.grad_sink
+        if old is not None and old is not self and isinstance(old, GradReducer) and any(p in old._owner for p in ps):
+            old.close()
         _F.grad_sink = self  # weight-gradient GEMMs now target the bucket views directly
 
     # ---- step protocol:  zero_grad() ... backward() ... wait() ... optimizer.step() ----
@@ -84,7 +89,7 @@ class GradReducer:
         """No memset: every view is either overwritten by its first gradient of the step or zeroed in wait()."""
         self._written.clear()
         for b in self.buckets:
-            b.pending = len(b.params)
+            b.ready.clear()
             b.work = None
             for p in b.params:
                 p.grad = None
@@ -117,9 +122,12 @@ class GradReducer:
         self._count(p)
 
     def _count(self, p: torch.nn.Parameter):
+        # per-parameter ready flags, not a counter: under no_sync() accumulation a parameter reports once per micro-batch,
+        # and the flags are reset when the synchronising backward begins (no_sync().__exit__), so the hooks of THAT
+        # backward launch each bucket as its last gradient arrives (the overlap) instead of everything serialising in wait()
         b = self._owner[p]
-        b.pending -= 1
-        if b.pending == 0 and self.sync and (self.world > 1 or self.force):
+        b.ready.add(id(p))
+        if len(b.ready) == len(b.params) and b.work is None and self.sync and (self.world > 1 or self.force):
             self._launch(b)
 
     def _launch(self, b: _Bucket):
@@ -149,7 +157,7 @@ class GradReducer:
                     b.flat.div_(self.world)
                     b._needs_div = False
         for b in self.buckets:
-            b.pending = len(b.params)
+            b.ready.clear()
 
     def close(self):
         """Detach from autograd and from the weight-gradient GEMMs (the parameters keep their current .grad views)."""
@@ -170,6 +178,8 @@ class GradReducer:
 
             def __exit__(self_inner, *a):
                 red.sync = True
+                for b in red.buckets:   # the next backward is the synchronising one: count its gradients from zero
+                    b.ready.clear()
                 return False
 
         return _Ctx()

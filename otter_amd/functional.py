@@ -319,7 +319,9 @@ def flash_self_attention(qkv, n_heads, slopes, key_valid, scale, causal=True):
 class CrossEntropyBf16Fn(torch.autograd.Function):
     """Mean token cross-entropy (ignore_index -100) on bf16 logits [rows, V] without materialising an fp32 copy
     (mpt/modeling_mpt.py:428-435 once the labels are rolled).  fp32 arithmetic on the bf16 values = what
-    F.cross_entropy(logits.float(), labels) computes; the gradient is produced directly in bf16."""
+    F.cross_entropy(logits.float(), labels) computes; the gradient is produced directly in bf16.  Any negative label is
+    ignored (torch: only -100, others assert); a label >= V makes the loss NaN (torch: device assert); an all-ignored batch
+    returns NaN like torch."""
 
     @staticmethod
     def forward(ctx, logits2d, labels):
@@ -334,7 +336,8 @@ class CrossEntropyBf16Fn(torch.autograd.Function):
                                                   rows, V, K_.stream()), "cross_entropy_fwd")
         n_valid = (labels >= 0).sum().to(torch.float32)
         ctx.save_for_backward(logits2d, labels, lse, n_valid)
-        return nll.sum() / n_valid.clamp(min=1.0)
+        # no clamp: a batch with every label ignored is 0 / 0 = NaN, exactly F.cross_entropy's mean over zero rows
+        return nll.sum() / n_valid
 
     @staticmethod
     def backward(ctx, dloss):

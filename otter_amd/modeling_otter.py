@@ -337,16 +337,27 @@ class OtterStubTokenizer:
 
 
 def _load_tokenizer(name: str, vocab_size: int):
-    try:
+    """modeling_otter.py:750-757.  The stub is used ONLY when the tokenizer files are not on this machine (OSError from
+    `local_files_only=True`: benches and tests run without network) or on explicit request (OTTER_STUB_TOKENIZER=1) -- and
+    says so; any other failure (a broken tokenizers install, a corrupt file) propagates, because the stub's hard-coded
+    special-token ids would silently change <image> / <|endofchunk|> (and alias real ids of a LLaMA vocabulary)."""
+    import os
+    import warnings
+
+    if os.environ.get("OTTER_STUB_TOKENIZER") != "1":
         from transformers import AutoTokenizer
 
-        tok = AutoTokenizer.from_pretrained(name, local_files_only=True)
-        tok.add_special_tokens({"additional_special_tokens": ["<|endofchunk|>", "<image>", "<answer>"]})
-        if tok.pad_token is None:
-            tok.add_special_tokens({"pad_token": "<PAD>"})
-        return tok
-    except Exception:
-        return OtterStubTokenizer(vocab_size)
+        try:
+            tok = AutoTokenizer.from_pretrained(name, local_files_only=True)
+        except OSError as e:
+            warnings.warn("otter_amd: tokenizer files for %r not found locally (%s); using OtterStubTokenizer "
+                          "(special-token ids only)" % (name, type(e).__name__), stacklevel=2)
+        else:
+            tok.add_special_tokens({"additional_special_tokens": ["<|endofchunk|>", "<image>", "<answer>"]})
+            if tok.pad_token is None:
+                tok.add_special_tokens({"pad_token": "<PAD>"})
+            return tok
+    return OtterStubTokenizer(vocab_size)
 
 
 def _use_hip_rmsnorm(lang_encoder: nn.Module) -> None:

@@ -58,6 +58,10 @@ class MPTConfig(PretrainedConfig):
                                       "(multihead, causal, no qk_ln / clip_qkv / prefix_lm / sequence_id)")
         if not a["alibi"]:
             raise NotImplementedError("learned position embeddings (alibi=False) are not implemented")
+        if self.resid_pdrop or self.emb_pdrop or a["attn_pdrop"]:
+            # the host never applies dropout (OTTER-MPT7B: all three are 0, mpt config :60-62,74); a non-zero value would
+            # silently train differently from the reference
+            raise NotImplementedError("resid_pdrop / emb_pdrop / attn_pdrop != 0 are not implemented in otter_amd's MPT host")
         if self.norm_type not in ("low_precision_layernorm", "layernorm"):
             raise NotImplementedError(f"norm_type {self.norm_type}")
 

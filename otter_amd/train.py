@@ -80,6 +80,25 @@ class TrainStep:
         # single rank: gradients stay ordinary .grad tensors (no bucket indirection, nothing to reduce)
         self.reducer = GradReducer(self.params, bucket_bytes, process_group, force=force_reducer) if (self.world > 1 or force_reducer) else None
 
+    def close(self):
+        """Detach the DP reducer's autograd hooks and gradient sink (idempotent).  Call before building another TrainStep /
+        GradReducer over the same model; also runs when the object is collected."""
+        red, self.reducer = getattr(self, "reducer", None), None
+        if red is not None:
+            red.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def no_sync(self):
+        """Micro-batch accumulation context (accelerate.no_sync / DDP.no_sync): gradients accumulate locally, no collective."""
+        import contextlib
+
+        return self.reducer.no_sync() if self.reducer is not None else contextlib.nullcontext()
+
     def zero_grad(self):
         if self.reducer is not None:
             self.reducer.zero_grad()

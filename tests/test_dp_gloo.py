@@ -52,6 +52,33 @@ def _worker(rank, world, port, q):
         allg = [torch.zeros_like(g_local) for _ in range(world)]
         dist.all_gather(allg, g_local)
         assert not torch.allclose(allg[0], allg[1])
+        # gradient accumulation: one no_sync micro-batch + one synchronising micro-batch == the full-batch mean gradient x 2/2,
+        # and the synchronising backward launches every bucket FROM ITS HOOKS (overlap), not from wait()
+        red.zero_grad()
+        halves = [(X[rank::world][:2], Y[rank::world][:2]), (X[rank::world][2:], Y[rank::world][2:])]
+        with red.no_sync():
+            (((net(halves[0][0]) - halves[0][1]) ** 2).mean() * 0.5).backward()
+        assert all(b.work is None for b in red.buckets)
+        (((net(halves[1][0]) - halves[1][1]) ** 2).mean() * 0.5).backward()
+        assert all(b.work is not None for b in red.buckets), "buckets must launch from the hooks of the synchronising backward"
+        red.wait()
+        for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+            if p.requires_grad:
+                assert torch.allclose(p.grad, pr.grad, atol=1e-6), n
+        # a second reducer over the same parameters detaches the first one (no double counting, no rebinding to old buckets)
+        from otter_amd import functional as OF
+
+        red2 = GradReducer(net.parameters(), bucket_bytes=1 << 20)
+        assert OF.grad_sink is red2 and red._hooks == []
+        red2.zero_grad()
+        ((net(X[rank::world]) - Y[rank::world]) ** 2).mean().backward()
+        red2.wait()
+        for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+            if p.requires_grad:
+                assert torch.allclose(p.grad, pr.grad, atol=1e-6), n
+                assert p.grad.data_ptr() == red2._view[p].data_ptr()
+        red2.close()
+        assert OF.grad_sink is None
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

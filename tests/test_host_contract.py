@@ -156,3 +156,55 @@ def test_llama_host_state_dict_contract():
     assert got == want
     assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == ref["trainable"]
     assert model.perceiver.frame_embs.shape == (4, 1024)
+
+
+def test_fused_adamw_is_a_torch_optimizer():
+    """the recipe wraps its optimizer in LambdaLR-style schedulers (get_cosine/linear_schedule_with_warmup,
+    instruction_following.py:476-489) and accelerate.prepare(); both isinstance-check torch.optim.Optimizer.  Construction,
+    scheduler stepping and the state-dict layout need no GPU (step() does and says so)."""
+    from otter_amd.optim import FusedAdamW
+
+    ps = [torch.nn.Parameter(torch.randn(4, 4)), torch.nn.Parameter(torch.randn(3))]
+    opt = FusedAdamW([{"params": ps[:1], "weight_decay": 0.1}, {"params": ps[1:], "weight_decay": 0.0}], lr=1e-3, max_grad_norm=1.0)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: min(1.0, (step + 1) / 4))
+    assert opt.param_groups[0]["lr"] == pytest.approx(2.5e-4)
+    ref = torch.optim.AdamW([{"params": ps[:1], "weight_decay": 0.1}, {"params": ps[1:], "weight_decay": 0.0}], lr=1e-3)
+    for p in ps:
+        p.grad = torch.zeros_like(p)
+    ref.step()
+    opt.load_state_dict(ref.state_dict())   # a torch AdamW checkpoint loads
+    st = opt.state[ps[0]]
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 1.0
+    ref.load_state_dict(opt.state_dict())   # ... and ours loads into torch AdamW
+    sched.step()
+    with pytest.raises(Exception):          # no CPU path: step() refuses non-GPU tensors
+        opt.step()
+
+
+def test_mpt_config_rejects_dropout():
+    from otter_amd.mpt import MPTConfig
+
+    MPTConfig(d_model=64, n_heads=4, n_layers=1)
+    for kw in (dict(resid_pdrop=0.1), dict(emb_pdrop=0.1), dict(attn_config=dict(attn_pdrop=0.1))):
+        with pytest.raises(NotImplementedError):
+            MPTConfig(d_model=64, n_heads=4, n_layers=1, **kw)
+
+
+def test_tokenizer_fallback_is_explicit(monkeypatch):
+    """The stub tokenizer is used for missing local files (with a warning) or on request, never for arbitrary failures."""
+    import transformers
+
+    from otter_amd import modeling_otter as MO
+
+    with pytest.warns(UserWarning, match="OtterStubTokenizer"):
+        assert isinstance(MO._load_tokenizer("no/such-tokenizer", 50432), MO.OtterStubTokenizer)
+
+    def boom(*a, **k):
+        raise RuntimeError("broken tokenizers install")
+
+    monkeypatch.setattr(transformers.AutoTokenizer, "from_pretrained", boom)
+    with pytest.raises(RuntimeError):
+        MO._load_tokenizer("mosaicml/mpt-7b-instruct", 50432)
+    monkeypatch.setenv("OTTER_STUB_TOKENIZER", "1")
+    assert isinstance(MO._load_tokenizer("mosaicml/mpt-7b-instruct", 50432), MO.OtterStubTokenizer)
