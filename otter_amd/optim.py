@@ -37,9 +37,12 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        for st in self.state.values():  # torch casts floating-point state to the parameter's device/dtype; keep `step` on the host
-            if "step" in st and torch.is_tensor(st["step"]):
-                st["step"] = st["step"].detach().to("cpu", torch.float32)
+        # torch only casts (`.to()` returns the SAME tensor when nothing changes): a state dict handed over in memory would
+        # leave `step` / moments shared with the optimizer it came from, and two optimizers stepping one counter.  Own copies.
+        for st in self.state.values():
+            for k, v in list(st.items()):
+                if torch.is_tensor(v):
+                    st[k] = v.detach().to("cpu", torch.float32).clone() if k == "step" else v.detach().clone(memory_format=torch.contiguous_format)
         self._tables = None
 
     # ---- tables: block -> (tensor, chunk) maps once per set of live tensors; every pointer column every step ----

@@ -183,10 +183,10 @@ def test_llama_ops_golden(ops):
 # GEMM (all variants, all epilogues)
 # ----------------------------------------------------------------------------------------------------------------------
 
-GEMM_SHAPES = [(48, 128, 48), (200, 136, 328), (257, 512, 64), (64, 384, 1024), (520, 264, 200)]
+GEMM_SHAPES = [(48, 128, 48), (200, 136, 328), (257, 512, 64), (64, 384, 1024), (520, 264, 200), (300, 520, 256), (513, 260, 128)]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
 def test_gemm_bf16_store(ops, variant, M, N, Kd):
     ops.set_gemm_variant(variant)
@@ -214,14 +214,14 @@ def test_gemm_f32_store(ops, M, N, Kd):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_gemm_epilogues(ops, dt, variant):
     from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
 
     ops.set_gemm_variant(variant)
     try:
         r = rng(77 + variant)
-        M, N, Kd = 300, 264, 136
+        M, N, Kd = 300, 264, (256 if variant >= 17 else 136)  # variants 17/18 need K % 128 == 0 (else it defers to 13)
         tdt = torch.float32 if dt == "f32" else torch.bfloat16
         A = r.standard_normal((M, Kd)).astype(np.float32) * 0.3
         B = r.standard_normal((N, Kd)).astype(np.float32) * 0.3
@@ -270,7 +270,7 @@ def test_gemm_big_variants_agree(ops):
     B = to_dev(r.standard_normal((N, Kd)), torch.bfloat16)
     ref = host(A).astype(np.float64) @ host(B).astype(np.float64).T
     outs = []
-    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
+    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18):
         ops.set_gemm_variant(v)
         outs.append(ops.gemm_nt(A, B, out_dtype=torch.float32))
     ops.set_gemm_variant(0)

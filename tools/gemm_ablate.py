@@ -2,7 +2,8 @@
 construction; timing only).  Usage: gemm_ablate.py [variant] -- run once per build, e.g.
     for m in 0 1 2 3 4 8 9 10; do python -m otter_amd.build --diag $m; done            (here, cross-compiled)
     for m in 0 1 2 3 4 8 9 10; do OTTER_LIB_PATH=otter_amd/lib/libotter_hip_diag$m.so python tools/gemm_ablate.py 10; done
-mask bits: 1 = no DMA, 2 = no MFMA, 4 = no epilogue (one stripe of four), 8 = no LDS fragment reads."""
+mask bits: 1 = no DMA, 2 = no MFMA, 4 = no epilogue traffic, 8 = no LDS fragment reads, 16 = no epilogue, 128 = plain instead of
+non-temporal stores in the fused tail (this one computes correct results)."""
 import json, os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
