@@ -75,6 +75,7 @@ SIGNATURES = {
     "otter_gemm_nt": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _int, C.POINTER(EpilogueArgs), _vp]),
     "otter_gemm_set_variant": (_int, [_int]),
     "otter_gemm_set_debug": (_int, [_int]),
+    "otter_gemm_read_timeline": (_int, [_vp, _int]),
     "otter_reduce_partials": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
     "otter_transpose": (_int, [_vp, _i64, _int, _vp, _i64, _vp, _i64, _int, _i64, _i64, _vp]),
     "otter_cast": (_int, [_vp, _int, _vp, _int, _i64, _vp]),

@@ -32,13 +32,16 @@ __host__ __device__ static inline int64_t cdiv64(int64_t a, int64_t b) { return 
 typedef uint16_t bf16_t;
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// gfx950 converts in hardware: v_cvt_pk_bf16_f32 (two values per instruction, round-to-nearest-even, NaN stays NaN).  The
+// software form this replaces (add 0x7fff + lsb, NaN branch) was ~10 VALU + an exec-mask branch PER ELEMENT: thousands of
+// cycles in every output tile of the GEMM tails, where one wave per SIMD has nothing to hide them behind.
+typedef __attribute__((ext_vector_type(2))) float otter_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 otter_bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const otter_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, otter_bf16x2_t));
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 // scalar typed access through a runtime dtype tag (used only on cold / tail paths)
 __device__ __forceinline__ float ld_as_f32(const void* p, int64_t i, int dtype) {

@@ -22,6 +22,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 thread_local char g_otter_err[512] = {0};
 
+// Diagnostics (otter_gemm_set_debug bit 64 + otter_gemm_read_timeline): tile-phase timestamps (s_memtime, shader cycles) of
+// the one-wave-per-SIMD kernels, blocks 0 and 131, every wave, the first 8 tiles of the block:
+// [block sel 2][wave 4][tile 8][mark 8] -- marks: 0 tile start, 1 prologue done, 2 K loop done, 3 tail done, 4 tile end.
+__device__ unsigned long long g_gemm_timeline[2 * 4 * 8 * 8];
+
 namespace {
 
 struct GemmArgs {
@@ -296,6 +301,70 @@ __device__ __forceinline__ void block_partial(const GemmArgs& g, float part, flo
         for (int w = 0; w < NWAVES; ++w) t += red[w];
         g.partial[slot] = t;
     }
+}
+
+// ---- fast tail of the one-wave-per-SIMD kernels (variants 17-20), FULL tiles only ----
+// With 8 waves per CU the stripe loop above hides its own latencies (another wave always has something to issue); with one
+// wave per SIMD every ds_write -> ds_read -> global access chain is exposed, and the run-time switches of the generic tail
+// (output dtype, bounds, wide/narrow) sit inside its loops: the K sweep of tools/gemm_ksweep.py priced the fixed part of a
+// variant-18 launch at 84 us against 46 us for the 8-wave kernel and 36 us for hipBLASLt.  Here the tile is known to be
+// in bounds, the output dtype is a template parameter, the per-stripe loop is fully unrolled (all LDS reads of a stripe are
+// issued before the first one is consumed) and consecutive stripes alternate between TWO parking buffers, so the next
+// stripe is parked while the current one's global accesses are in flight.  Same arithmetic, same access shapes (whole
+// cache lines per row run) as epilogue_stripe.
+template <int EPI, bool CBF16>
+__device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const float* __restrict__ blk, int64_t m_base, int64_t n_base,
+                                                  int lane) {
+    float part = 0.f;
+    g.cdt = CBF16 ? OTTER_BF16 : OTTER_F32;  // compile-time constant from here on: the dtype switches of load/store fold away
+    if constexpr (CBF16) {
+        float v[4][8];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = (lane >> 3) + 8 * it, c = (lane & 7) * 8;
+            const float4 t0 = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
+            const float4 t1 = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c + 4);
+            v[it][0] = t0.x; v[it][1] = t0.y; v[it][2] = t0.z; v[it][3] = t0.w;
+            v[it][4] = t1.x; v[it][5] = t1.y; v[it][6] = t1.z; v[it][7] = t1.w;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = (lane >> 3) + 8 * it, c = (lane & 7) * 8;
+            part += epilogue8<EPI>(g, s, m_base + r, n_base + c, v[it]);
+        }
+    } else {
+        float v[8][4];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = (lane >> 4) + 4 * it, c = (lane & 15) * 4;
+            const float4 t = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
+            v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = (lane >> 4) + 4 * it, c = (lane & 15) * 4;
+            part += epilogue4<EPI>(g, s, m_base + r, n_base + c, v[it]);
+        }
+    }
+    return part;
+}
+
+// whole 128x128 wave tile: 8 stripes of 32 rows x 64 columns, two parking buffers per wave
+template <int EPI, bool CBF16>
+__device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk2 /* 2 stripes */,
+                                                int64_t m_wave, int64_t n_wave, int lane) {
+    float part = 0.f;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        const int mi = st >> 1, np = st & 1;
+        float* blk = blk2 + (st & 1) * (32 * EPI_LD);
+        park_block(blk, acc[mi][2 * np], lane, 0);
+        park_block(blk, acc[mi][2 * np + 1], lane, 32);
+        __builtin_amdgcn_wave_barrier();
+        part += tail_stripe_full<EPI, CBF16>(g, s, blk, m_wave + mi * 32, n_wave + np * 64, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+    return part;
 }
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int bid, int& tile_m, int& tile_n) {
@@ -1479,6 +1548,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
         // ---- epilogue: the ring is free (every DMA retired, every wave past the last barrier, every fragment read consumed) ----
         float part = 0.f;
         float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+        // full in-bounds tile with the wide bf16 / 16-byte f32 access shapes -> unrolled double-buffered tail, else the generic one
+        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (OTTER_DIAG & (4 | 16)) == 0 &&
+                          (g.cdt == OTTER_F32 || g.wide);
+        if (full) {
+            float* blk2 = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_LD);
+            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
+            else part = tail_wave_full<EPI, false>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
+        } else {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             if constexpr ((OTTER_DIAG & 16) != 0) {
@@ -1496,6 +1573,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
                 part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 128 + mi * 32, n0 + wn * 128 + np * 64, lane);
                 __builtin_amdgcn_wave_barrier();
             }
+        }
         }
         if constexpr ((OTTER_DIAG & 20) != 0) {  // keep `part` (hence the accumulators) observable
             if (part == 12345.678f) reinterpret_cast<float*>(g.C)[threadIdx.x] = part;
@@ -1520,7 +1598,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
 // slots, at most one filler each) -- generated by tools/gen/gemm_r4_schedule.py, see its header.
 // Requires K % 128 == 0 and operands spanning < 4 GB.
 // ------------------------------------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, int SCH>
 __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, NT = 256;
     constexpr int TILE = (BM + BN) * 128;  // 64 KB: [256 A rows ; 256 B rows] x 128 B
@@ -1549,6 +1627,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
         rb_hi[ks] = rb[ks] + TILE;
         asm volatile("" : "+v"(ra_hi[ks]), "+v"(rb_hi[ks]));
     }
+#define TMARK(K_)                                                                                                         \
+    do {                                                                                                                  \
+        if ((g.dbg & 64) && (blockIdx.x == 0 || blockIdx.x == 131) && lane == 0 && tcount < 8)                            \
+            g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + (K_)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+    int tcount = 0;
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define LDF(dst, base_lo, base_hi, BUFV, KS, I)                                                                           \
     do {                                                                                                                  \
@@ -1561,6 +1645,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
         int tile_m, tile_n;
         tile_of_block(g, vb, tile_m, tile_n);
         const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+        TMARK(0);
         uint32_t oa[8], ob[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1611,13 +1696,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
             LDF(fn[0][i], rb, rb_hi, 0, 0, i);
             LDF(fm[0][i], ra, ra_hi, 0, 0, i);
         }
+        TMARK(1);
 #define MMA(KS, MI, NI)                                                                                                   \
     do {                                                                                                                  \
         if constexpr ((OTTER_DIAG & 2) == 0)                                                                              \
             acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0);          \
     } while (0)
 // ---- GENERATED by tools/gen/gemm_r4_schedule.py (do not edit by hand) ----
-#define KTILE(BUF, TV, DMA, NEXT)                                                                                                                                                                                                      \
+#define KTILE_S0(BUF, TV, DMA, NEXT)                                                                                                                                                                                                   \
     do {                                                                                                                                                                                                                               \
         MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                                                                 \
         MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                                                                                                                                 \
@@ -1684,20 +1770,172 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
         MMA(3, 2, 3); SB();                                                                                                                                                                                                            \
         MMA(3, 3, 3); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                                                             \
     } while (0)
+#define KTILE_S1(BUF, TV, DMA, NEXT)                                                                                                                                                                                                   \
+    do {                                                                                                                                                                                                                               \
+        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                      \
+        MMA(0, 1, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                      \
+        MMA(0, 0, 1); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                      \
+        MMA(0, 1, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                      \
+        MMA(0, 2, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                                                                                      \
+        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                                                                                      \
+        MMA(0, 3, 0); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                                                                                      \
+        MMA(0, 3, 1); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                                                                                      \
+        MMA(0, 0, 2); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                                                                                      \
+        MMA(0, 1, 2); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                                                                                      \
+        MMA(0, 2, 2); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                                                                                      \
+        MMA(0, 3, 2); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                                                                                      \
+        MMA(0, 0, 3); SB();                                                                                                                                                                                                            \
+        MMA(0, 1, 3); SB();                                                                                                                                                                                                            \
+        MMA(0, 2, 3); SB();                                                                                                                                                                                                            \
+        MMA(0, 3, 3); SB();                                                                                                                                                                                                            \
+        MMA(1, 0, 0); SB();                                                                                                                                                                                                            \
+        MMA(1, 1, 0); SB();                                                                                                                                                                                                            \
+        MMA(1, 0, 1); SB();                                                                                                                                                                                                            \
+        MMA(1, 1, 1); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                                                                     \
+        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                                                                      \
+        MMA(1, 2, 1); SB();                                                                                                                                                                                                            \
+        MMA(1, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                                                                      \
+        MMA(1, 3, 1); SB();                                                                                                                                                                                                            \
+        MMA(1, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                                                                      \
+        MMA(1, 1, 2); SB();                                                                                                                                                                                                            \
+        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                                                                      \
+        MMA(1, 3, 2); SB();                                                                                                                                                                                                            \
+        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                                                                      \
+        MMA(1, 1, 3); SB();                                                                                                                                                                                                            \
+        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                                                                      \
+        MMA(1, 3, 3); SB();                                                                                                                                                                                                            \
+        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                                                                      \
+        MMA(2, 1, 0); SB();                                                                                                                                                                                                            \
+        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                                                                      \
+        MMA(2, 1, 1); SB();                                                                                                                                                                                                            \
+        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                                                                      \
+        MMA(2, 2, 1); SB();                                                                                                                                                                                                            \
+        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                                                                      \
+        MMA(2, 3, 1); SB();                                                                                                                                                                                                            \
+        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                                                                     \
+        MMA(2, 1, 2); SB();                                                                                                                                                                                                            \
+        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
+        MMA(2, 3, 2); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                                                             \
+        MMA(2, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                                                                     \
+        MMA(2, 1, 3); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                                                             \
+        MMA(2, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                                                                     \
+        MMA(2, 3, 3); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                                                             \
+        MMA(3, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                                                                     \
+        MMA(3, 1, 0); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                                                             \
+        MMA(3, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                                                                     \
+        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                                                             \
+        MMA(3, 2, 0); SB();                                                                                                                                                                                                            \
+        MMA(3, 2, 1); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                                                             \
+        MMA(3, 3, 0); SB();                                                                                                                                                                                                            \
+        MMA(3, 3, 1); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                                                             \
+        MMA(3, 0, 2); SB();                                                                                                                                                                                                            \
+        MMA(3, 1, 2); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                                                             \
+        MMA(3, 2, 2); SB();                                                                                                                                                                                                            \
+        MMA(3, 3, 2); SB();                                                                                                                                                                                                            \
+        MMA(3, 0, 3); SB();                                                                                                                                                                                                            \
+        MMA(3, 1, 3); SB();                                                                                                                                                                                                            \
+        MMA(3, 2, 3); SB();                                                                                                                                                                                                            \
+        MMA(3, 3, 3); SB();                                                                                                                                                                                                            \
+    } while (0)
+#define KTILE_S2(BUF, TV, DMA, NEXT)                                                                                                                                                            \
+    do {                                                                                                                                                                                        \
+        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                                                                                          \
+        MMA(0, 0, 1); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 1, 1); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                                                                                          \
+        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB();                                                                                                                          \
+        MMA(0, 3, 0); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 3, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                                                                                          \
+        MMA(0, 0, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 1, 2); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB();                                                                                                                          \
+        MMA(0, 2, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 3, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                                                                                          \
+        MMA(0, 0, 3); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 1, 3); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB();                                                                                                                          \
+        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 3, 3); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                                                                                          \
+        MMA(1, 0, 0); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB();                                                                                                                          \
+        MMA(1, 1, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                                                                                          \
+        MMA(1, 0, 1); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB();                                                                                                                          \
+        MMA(1, 1, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                                                                                          \
+        MMA(1, 2, 0); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB();                                                                                                                          \
+        MMA(1, 2, 1); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                                                                                          \
+        MMA(1, 3, 0); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB();                                                                                                                          \
+        MMA(1, 3, 1); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                                                                                          \
+        MMA(1, 0, 2); SB();                                                                                                                                                                     \
+        MMA(1, 1, 2); SB();                                                                                                                                                                     \
+        MMA(1, 2, 2); SB();                                                                                                                                                                     \
+        MMA(1, 3, 2); SB();                                                                                                                                                                     \
+        MMA(1, 0, 3); SB();                                                                                                                                                                     \
+        MMA(1, 1, 3); SB();                                                                                                                                                                     \
+        MMA(1, 2, 3); SB();                                                                                                                                                                     \
+        MMA(1, 3, 3); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
+        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
+        MMA(2, 1, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
+        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
+        MMA(2, 1, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
+        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
+        MMA(2, 2, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
+        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
+        MMA(2, 3, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
+        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
+        MMA(2, 1, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
+        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
+        MMA(2, 3, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
+        MMA(2, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
+        MMA(2, 1, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
+        MMA(2, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
+        MMA(2, 3, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
+        MMA(3, 0, 0); SB();                                                                                                                                                                     \
+        MMA(3, 1, 0); SB();                                                                                                                                                                     \
+        MMA(3, 0, 1); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
+        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                       \
+        MMA(3, 2, 0); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                       \
+        MMA(3, 2, 1); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                       \
+        MMA(3, 3, 0); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                       \
+        MMA(3, 3, 1); SB();                                                                                                                                                                     \
+        MMA(3, 0, 2); SB();                                                                                                                                                                     \
+        MMA(3, 1, 2); SB();                                                                                                                                                                     \
+        MMA(3, 2, 2); SB();                                                                                                                                                                     \
+        MMA(3, 3, 2); SB();                                                                                                                                                                     \
+        MMA(3, 0, 3); SB();                                                                                                                                                                     \
+        MMA(3, 1, 3); SB();                                                                                                                                                                     \
+        MMA(3, 2, 3); SB();                                                                                                                                                                     \
+        MMA(3, 3, 3); SB();                                                                                                                                                                     \
+    } while (0)
 // ---- end of generated schedule ----
-        int t = 0;
-        for (; t + 2 < nk; t += 2) {
-            KTILE(0, t, true, true);
-            KTILE(1, t + 1, true, true);
-        }
-        KTILE(0, t, false, true);
-        KTILE(1, t + 1, false, false);
-#undef KTILE
+#define KLOOP(KT)                                   \
+    do {                                            \
+        int t = 0;                                  \
+        for (; t + 2 < nk; t += 2) {                \
+            KT(0, t, true, true);                   \
+            KT(1, t + 1, true, true);               \
+        }                                           \
+        KT(0, t, false, true);                      \
+        KT(1, t + 1, false, false);                 \
+    } while (0)
+        if constexpr (SCH == 0) KLOOP(KTILE_S0);
+        else if constexpr (SCH == 1) KLOOP(KTILE_S1);
+        else KLOOP(KTILE_S2);
+#undef KLOOP
+#undef KTILE_S0
+#undef KTILE_S1
+#undef KTILE_S2
 #undef MMA
 
         // ---- epilogue: both buffers are dead (every fragment read retired before barrier #1 of the last K-tile, no DMA in flight) ----
+        TMARK(2);
         float part = 0.f;
         float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+        // full in-bounds tile with the wide bf16 / 16-byte f32 access shapes -> unrolled double-buffered tail, else the generic one
+        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (OTTER_DIAG & (4 | 16)) == 0 &&
+                          (g.cdt == OTTER_F32 || g.wide);
+        if (full) {
+            float* blk2 = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_LD);
+            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
+            else part = tail_wave_full<EPI, false>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
+        } else {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             if constexpr ((OTTER_DIAG & 16) != 0) {
@@ -1716,14 +1954,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        }
         if constexpr ((OTTER_DIAG & 20) != 0) {
             if (part == 12345.678f) reinterpret_cast<float*>(g.C)[threadIdx.x] = part;
         }
+        TMARK(3);
         block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
         __syncthreads();  // the next tile's prologue DMA overwrites the stripes
+        TMARK(4);
+        ++tcount;
     }
 #undef LDF
 #undef SB
+#undef TMARK
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1819,23 +2062,24 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 int g_variant = 0;
 int g_debug = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_F32 = 100 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
     if (ab_dtype == OTTER_F32) return CFG_F32;
     int v = g_variant;
     if (v == 0) {
-        // interleaved A/B medians on MI355X (tools/gemm_ab.py): the balanced phased schedule with buffer
-        // addressing wins on all three FFN shapes (1.31-1.41 PF vs 1.16-1.34 for variant 10, 1.10-1.22 for the ring)
-        if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = CFG_PHLB;
+        // interleaved A/B medians on MI355X (tools/gemm_ab.py): round 2's one-wave-per-SIMD kernel with the
+        // register-resident K-tile (variant 18) beats round 1's balanced 8-wave phased schedule (variant 13) on all three
+        // FFN shapes (1.29 / 1.49 / 1.43 PF vs 1.19 / 1.39 / 1.37 on one box); it needs K % 128 == 0, else 13 stays
+        if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = (K % 128 == 0 && !wide) ? CFG_R4 : CFG_PHLB;
         else v = CFG_128;
     }
     if ((v == CFG_MS4 || v == CFG_MS5 || v == CFG_MS5B) && (K % 32 != 0)) v = CFG_256_GLDS;
     if (v == CFG_WS && K % 64 != 0) v = CFG_256;
     const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB || v == CFG_PH2B || v == CFG_PHDB;
     if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
-    if ((v == CFG_Q4 || v == CFG_R4) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
+    if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
     if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
@@ -1930,12 +2174,19 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
 #undef LAUNCH_MS
         return OTTER_OK;
     }
-    if (cfg == CFG_R4) {
-        static bool once = false;
+    if (cfg == CFG_R4 || cfg == CFG_R4B || cfg == CFG_R4C) {
         const int smem = 2 * 65536;  // two K-tile buffers; the epilogue stripes alias the first
-        if (!once) { int rc = set_smem(gemm_bf16_r4_kernel<EPI>, smem); if (rc) return rc; once = true; }
         unsigned pg = grid.x < 256u ? grid.x : 256u;
-        hipLaunchKernelGGL((gemm_bf16_r4_kernel<EPI>), dim3(pg), dim3(256), smem, st, g);
+#define LAUNCH_R4(SCH_)                                                                                                    \
+    do {                                                                                                                   \
+        static bool once = false;                                                                                          \
+        if (!once) { int rc = set_smem(gemm_bf16_r4_kernel<EPI, SCH_>, smem); if (rc) return rc; once = true; }            \
+        hipLaunchKernelGGL((gemm_bf16_r4_kernel<EPI, SCH_>), dim3(pg), dim3(256), smem, st, g);                            \
+    } while (0)
+        if (cfg == CFG_R4) LAUNCH_R4(0);
+        else if (cfg == CFG_R4B) LAUNCH_R4(1);
+        else LAUNCH_R4(2);
+#undef LAUNCH_R4
         return OTTER_OK;
     }
     if (cfg == CFG_Q4) {
@@ -1976,13 +2227,20 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 18) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 20) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }
 
+int otter_gemm_read_timeline(unsigned long long* out, int n) {
+    OTTER_REQUIRE(out && n > 0 && n <= 2 * 4 * 8 * 8, "gemm_read_timeline: n");
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_timeline), sizeof(unsigned long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) OTTER_FAIL(OTTER_ERR_LAUNCH, "hipMemcpyFromSymbol: %s", hipGetErrorString(e));
+    return OTTER_OK;
+}
+
 int otter_gemm_set_debug(int flags) {
-    g_debug = flags & 255;
+    g_debug = flags & 255;  // bit 64: tile-phase timeline of variants 18-20 (otter_gemm_read_timeline)
     g_narrow_epilogue = (flags & 256) ? 1 : 0;
     return OTTER_OK;
 }

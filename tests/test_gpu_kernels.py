@@ -186,7 +186,7 @@ def test_llama_ops_golden(ops):
 GEMM_SHAPES = [(48, 128, 48), (200, 136, 328), (257, 512, 64), (64, 384, 1024), (520, 264, 200), (300, 520, 256), (513, 260, 128)]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 @pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
 def test_gemm_bf16_store(ops, variant, M, N, Kd):
     ops.set_gemm_variant(variant)
@@ -214,7 +214,7 @@ def test_gemm_f32_store(ops, M, N, Kd):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20])
 def test_gemm_epilogues(ops, dt, variant):
     from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
 
@@ -262,6 +262,56 @@ def test_gemm_epilogues(ops, dt, variant):
         ops.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("variant", [17, 18, 19, 20])
+@pytest.mark.parametrize("out_dt", ["bf16", "f32"])
+def test_gemm_full_tile_fast_tail(ops, variant, out_dt):
+    """The one-wave-per-SIMD kernels take an unrolled, double-buffered tail on full in-bounds tiles: every epilogue kind and
+    both output dtypes against the 8-wave kernel (variant 13, generic tail) on a 512 x 768 x 256 problem -- same per-element
+    accumulation order, so the results must agree to the last bit -- and against the fp64 product."""
+    from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
+
+    r = rng(900 + variant)
+    M, N, Kd = 512, 768, 256
+    odt = torch.bfloat16 if out_dt == "bf16" else torch.float32
+    A = to_dev(bf16_round(r.standard_normal((M, Kd)) * 0.3), torch.bfloat16)
+    B = to_dev(bf16_round(r.standard_normal((N, Kd)) * 0.3), torch.bfloat16)
+    R = to_dev(r.standard_normal((M, N)).astype(np.float32))
+    aux = to_dev(bf16_round(r.standard_normal((M, N))), torch.bfloat16)
+    gate = to_dev(np.array([0.7], np.float32))
+    ref = host(A).astype(np.float64) @ host(B).astype(np.float64).T
+
+    def run(v):
+        ops.set_gemm_variant(v)
+        out = {}
+        out["store"] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_STORE, gate=gate)
+        C2 = torch.empty((M, N), dtype=odt, device=DEV)
+        out["gelu"] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_GELU, C2=C2)
+        out["gelu_pre"] = C2
+        out["res"] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_SCALE_RES, gate=gate, R=R)
+        for ag in (False, True):
+            part = torch.zeros(ops.gemm_num_partials(M, N, torch.bfloat16), dtype=torch.float32, device=DEV)
+            out["gbwd%d" % ag] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_GATE_BWD, gate=gate, aux=aux, aux_gelu=ag, partial=part)
+            out["gpart%d" % ag] = ops.reduce_partials(part, gate=gate)
+        if out_dt == "f32":
+            acc = out["store"].clone()
+            ops.gemm_nt(A, B, out=acc, kind=EPI_STORE, accumulate=True)
+            out["accum"] = acc
+        return out
+
+    try:
+        mine, base = run(variant), run(13)
+    finally:
+        ops.set_gemm_variant(0)
+    for k in base:
+        if k.startswith("gpart"):   # block partials are summed in a different order (4 vs 8 waves)
+            assert abs(float(mine[k][0]) - float(base[k][0])) <= 1e-4 * abs(float(base[k][0])) + 1e-4, k
+        else:
+            assert torch.equal(mine[k], base[k]), k
+    tol = 1e-2 if out_dt == "bf16" else 1e-4
+    assert relmax(host(mine["store"]), ref * np.tanh(0.7)) < tol
+    assert relmax(host(mine["gelu_pre"]), ref) < tol
+
+
 def test_gemm_big_variants_agree(ops):
     """All three bf16 schedules produce the same numbers on the FFN shape class (256-multiple tiles, K=1024)."""
     r = rng(3)
@@ -270,7 +320,7 @@ def test_gemm_big_variants_agree(ops):
     B = to_dev(r.standard_normal((N, Kd)), torch.bfloat16)
     ref = host(A).astype(np.float64) @ host(B).astype(np.float64).T
     outs = []
-    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18):
+    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20):
         ops.set_gemm_variant(v)
         outs.append(ops.gemm_nt(A, B, out_dtype=torch.float32))
     ops.set_gemm_variant(0)

@@ -1,0 +1,34 @@
+"""Tile-phase timeline of the one-wave-per-SIMD GEMM (variants 18-20): shader-clock timestamps at tile start / prologue done /
+K loop done / tail done / tile end for two blocks (otter_gemm_set_debug bit 64).  Usage: gemm_timeline.py [variant] [M N K]"""
+import ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from otter_amd import ops, _capi as K
+
+v = int(sys.argv[1]) if len(sys.argv) > 1 else 18
+M, N, Kd = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (4096, 16384, 4096)
+A = torch.randn(M, Kd, device="cuda").to(torch.bfloat16)
+B = torch.randn(N, Kd, device="cuda").to(torch.bfloat16)
+C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+ops.set_gemm_variant(v)
+for _ in range(3):
+    ops.gemm_nt(A, B, out=C)
+torch.cuda.synchronize()
+K.lib().otter_gemm_set_debug(64)
+ops.gemm_nt(A, B, out=C)
+torch.cuda.synchronize()
+K.lib().otter_gemm_set_debug(0)
+buf = np.zeros(512, dtype=np.uint64)
+K.check(K.lib().otter_gemm_read_timeline(buf.ctypes.data_as(ctypes.c_void_p), 512), "timeline")
+t = buf.reshape(2, 4, 8, 8).astype(np.int64)
+ntile = (M // 256) * (N // 256) // 256
+for b in range(2):
+    t0 = t[b, :, 0, 0].min()
+    print("block %d (cycles since its first tile start; wave 0 .. 3)" % (0 if b == 0 else 131))
+    for tile in range(min(ntile, 8)):
+        for w in range(4):
+            m = t[b, w, tile, :5] - t0
+            print("  tile %d wave %d: start %8d | prologue %6d | kloop %7d | tail %6d | sync %5d" %
+                  (tile, w, m[0], m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3]))
+ops.set_gemm_variant(0)
