@@ -312,56 +312,165 @@ __device__ __forceinline__ void block_partial(const GemmArgs& g, float part, flo
 // issued before the first one is consumed) and consecutive stripes alternate between TWO parking buffers, so the next
 // stripe is parked while the current one's global accesses are in flight.  Same arithmetic, same access shapes (whole
 // cache lines per row run) as epilogue_stripe.
-template <int EPI, bool CBF16>
-__device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const float* __restrict__ blk, int64_t m_base, int64_t n_base,
-                                                  int lane) {
-    float part = 0.f;
-    g.cdt = CBF16 ? OTTER_BF16 : OTTER_F32;  // compile-time constant from here on: the dtype switches of load/store fold away
-    if constexpr (CBF16) {
-        float v[4][8];
+// The fused tail in two phases, so that the global INPUT of a stripe (residual R, gate-backward aux, the C being accumulated
+// into) can be requested one stripe ahead of the arithmetic that consumes it: with one wave per SIMD an un-prefetched
+// load -> use chain exposes a full memory latency eight times per tile (gate-backward: 626 us per launch in situ against
+// 553 for the 8-wave kernel, whose two waves per SIMD cover each other).  NE = elements per lane per access (8 / 4).
+template <int EPI>
+__device__ __forceinline__ bool tail_input(const GemmArgs& g, const void*& p, int64_t& ld, int& dt) {
+    if constexpr (EPI == OTTER_EPI_STORE) { p = g.C; ld = g.ldc; dt = g.cdt; return g.accumulate != 0; }
+    else if constexpr (EPI == OTTER_EPI_SCALE_RES) { p = g.R; ld = g.ldr; dt = g.rdt; return true; }
+    else if constexpr (EPI == OTTER_EPI_GATE_BWD) { p = g.aux; ld = g.ldaux; dt = g.auxdt; return true; }
+    else { p = nullptr; ld = 0; dt = OTTER_F32; return false; }
+}
+// raw (unconverted) input of NE elements: the conversion to f32 stays with the consumer so that no use sits next to the load
+template <int NE>
+__device__ __forceinline__ void load_raw(const void* p, int64_t idx, int dt, uint4 (&raw)[2]) {
+    if (dt == OTTER_BF16) {
+        if constexpr (NE == 8) raw[0] = *reinterpret_cast<const uint4*>((const bf16_t*)p + idx);
+        else { const uint2 t = *reinterpret_cast<const uint2*>((const bf16_t*)p + idx); raw[0].x = t.x; raw[0].y = t.y; }
+    } else {
+        raw[0] = *reinterpret_cast<const uint4*>((const float*)p + idx);
+        if constexpr (NE == 8) raw[1] = *reinterpret_cast<const uint4*>((const float*)p + idx + 4);
+    }
+}
+template <int NE>
+__device__ __forceinline__ void cvt_raw(const uint4 (&raw)[2], int dt, float (&a)[NE]) {
+    if (dt == OTTER_BF16) {
+        const uint32_t w[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w};
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = (lane >> 3) + 8 * it, c = (lane & 7) * 8;
-            const float4 t0 = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
-            const float4 t1 = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c + 4);
-            v[it][0] = t0.x; v[it][1] = t0.y; v[it][2] = t0.z; v[it][3] = t0.w;
+        for (int i = 0; i < NE / 2; ++i) { a[2 * i] = __uint_as_float(w[i] << 16); a[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    } else {
+        a[0] = __uint_as_float(raw[0].x); a[1] = __uint_as_float(raw[0].y); a[2] = __uint_as_float(raw[0].z); a[3] = __uint_as_float(raw[0].w);
+        if constexpr (NE == 8) {
+            a[4] = __uint_as_float(raw[1].x); a[5] = __uint_as_float(raw[1].y); a[6] = __uint_as_float(raw[1].z); a[7] = __uint_as_float(raw[1].w);
+        }
+    }
+}
+// arithmetic + stores of NE consecutive output columns given the accumulator values v and the (already loaded) input a:
+// exactly epilogue4 / epilogue8 with their load taken out
+template <int EPI, int NE>
+__device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t m, int64_t n, const float (&v)[NE], const float (&a)[NE], bool has_in) {
+    float part = 0.f;
+    float o[NE];
+    if constexpr (EPI == OTTER_EPI_STORE) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) o[i] = has_in ? a[i] + s * v[i] : s * v[i];
+    } else if constexpr (EPI == OTTER_EPI_GELU) {
+        if (g.C2) {
+            if constexpr (NE == 8) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
+            else store4(g.C2, m * g.ldc2 + n, g.cdt, v);
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            float cdf, pdf;
+            gelu_cdf_pdf(v[i], cdf, pdf);
+            o[i] = v[i] * cdf;
+        }
+    } else if constexpr (EPI == OTTER_EPI_SCALE_RES) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) o[i] = v[i] * s + a[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (g.aux_gelu) {
+                float cdf, pdf;
+                gelu_cdf_pdf(a[i], cdf, pdf);
+                part += v[i] * (a[i] * cdf);
+                o[i] = s * v[i] * (cdf + a[i] * pdf);
+            } else {
+                part += v[i] * a[i];
+                o[i] = s * v[i];
+            }
+        }
+    }
+    if constexpr (NE == 8) store8w(g.C, m * g.ldc + n, g.cdt, o);
+    else store4(g.C, m * g.ldc + n, g.cdt, o);
+    return part;
+}
+
+template <bool CBF16>
+struct TailShape {  // bf16 output: 4 accesses of 8 columns per lane and stripe; f32 output: 8 accesses of 4 columns
+    static constexpr int NE = CBF16 ? 8 : 4, NIT = CBF16 ? 4 : 8;
+    static __device__ __forceinline__ int row(int lane, int it) { return CBF16 ? (lane >> 3) + 8 * it : (lane >> 4) + 4 * it; }
+    static __device__ __forceinline__ int col(int lane) { return CBF16 ? (lane & 7) * 8 : (lane & 15) * 4; }
+};
+
+template <int EPI, bool CBF16>
+__device__ __forceinline__ void tail_stripe_load(const void* p, int64_t ld, int dt, int64_t m_base, int64_t n_base, int lane,
+                                                 uint4 (&raw)[TailShape<CBF16>::NIT][2]) {
+    using T = TailShape<CBF16>;
+#pragma unroll
+    for (int it = 0; it < T::NIT; ++it) load_raw<T::NE>(p, (m_base + T::row(lane, it)) * ld + n_base + T::col(lane), dt, raw[it]);
+}
+
+template <int EPI, bool CBF16>
+__device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const float* __restrict__ blk, int64_t m_base, int64_t n_base, int lane,
+                                                  const uint4 (&raw)[TailShape<CBF16>::NIT][2], int in_dt, bool has_in) {
+    using T = TailShape<CBF16>;
+    float part = 0.f;
+    g.cdt = CBF16 ? OTTER_BF16 : OTTER_F32;  // compile-time constant from here on: the dtype switches of the stores fold away
+    float v[T::NIT][T::NE];
+#pragma unroll
+    for (int it = 0; it < T::NIT; ++it) {
+        const float* src = blk + T::row(lane, it) * EPI_LD + T::col(lane);
+        const float4 t0 = *reinterpret_cast<const float4*>(src);
+        v[it][0] = t0.x; v[it][1] = t0.y; v[it][2] = t0.z; v[it][3] = t0.w;
+        if constexpr (CBF16) {
+            const float4 t1 = *reinterpret_cast<const float4*>(src + 4);
             v[it][4] = t1.x; v[it][5] = t1.y; v[it][6] = t1.z; v[it][7] = t1.w;
         }
+    }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = (lane >> 3) + 8 * it, c = (lane & 7) * 8;
-            part += epilogue8<EPI>(g, s, m_base + r, n_base + c, v[it]);
-        }
-    } else {
-        float v[8][4];
+    for (int it = 0; it < T::NIT; ++it) {
+        float a[T::NE];
+        if (has_in) cvt_raw<T::NE>(raw[it], in_dt, a);
+        else {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = (lane >> 4) + 4 * it, c = (lane & 15) * 4;
-            const float4 t = *reinterpret_cast<const float4*>(blk + r * EPI_LD + c);
-            v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
+            for (int i = 0; i < T::NE; ++i) a[i] = 0.f;
         }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = (lane >> 4) + 4 * it, c = (lane & 15) * 4;
-            part += epilogue4<EPI>(g, s, m_base + r, n_base + c, v[it]);
-        }
+        part += tail_apply<EPI, T::NE>(g, s, m_base + T::row(lane, it), n_base + T::col(lane), v[it], a, has_in);
     }
     return part;
 }
 
-// whole 128x128 wave tile: 8 stripes of 32 rows x 64 columns, two parking buffers per wave
+// whole 128x128 wave tile = 8 stripes of 32 rows x 64 columns, FOUR parking buffers per wave: half of the wave tile is parked
+// in one go (32 ds_write_b128 with static accumulator indices -- a dynamically indexed accumulator array is demoted to
+// scratch, and so is one selected by a switch inside a loop: tried, 512 B of scratch per lane with accesses in the K loop),
+// then a RUN-TIME loop walks the four parked stripes with ONE copy of the stripe arithmetic (unrolling it eight times made
+// the GELU / gate-backward instantiations 22k-39k lines with 956 scratch accesses: 1150 us per launch in situ).  The
+// buffers are wave-private and a wave's LDS operations execute in order, so no barrier is needed between the phases.
+constexpr int TAIL_STRIPES = 4;
+constexpr int TAIL_LDS_BYTES = 4 * TAIL_STRIPES * 32 * EPI_LD * 4;  // 4 waves: 139264 B
+
 template <int EPI, bool CBF16>
-__device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk2 /* 2 stripes */,
+__device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4 /* 4 stripes */,
                                                 int64_t m_wave, int64_t n_wave, int lane) {
+    using T = TailShape<CBF16>;
     float part = 0.f;
+    const void* ip; int64_t ild; int idt;
+    const bool has_in = tail_input<EPI>(g, ip, ild, idt);
+    uint4 cur[T::NIT][2], nxt[T::NIT][2];
+    if (has_in) tail_stripe_load<EPI, CBF16>(ip, ild, idt, m_wave, n_wave, lane, cur);   // stripe 0
 #pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        const int mi = st >> 1, np = st & 1;
-        float* blk = blk2 + (st & 1) * (32 * EPI_LD);
-        park_block(blk, acc[mi][2 * np], lane, 0);
-        park_block(blk, acc[mi][2 * np + 1], lane, 32);
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int q = 0; q < TAIL_STRIPES; ++q) {
+            const int st = half * TAIL_STRIPES + q;
+            park_block(blk4 + q * (32 * EPI_LD), acc[st >> 1][2 * (st & 1)], lane, 0);
+            park_block(blk4 + q * (32 * EPI_LD), acc[st >> 1][2 * (st & 1) + 1], lane, 32);
+        }
         __builtin_amdgcn_wave_barrier();
-        part += tail_stripe_full<EPI, CBF16>(g, s, blk, m_wave + mi * 32, n_wave + np * 64, lane);
+#pragma unroll 1
+        for (int q = 0; q < TAIL_STRIPES; ++q) {
+            const int st = half * TAIL_STRIPES + q;
+            if (has_in && st + 1 < 8)   // request the next stripe's input before this stripe's arithmetic
+                tail_stripe_load<EPI, CBF16>(ip, ild, idt, m_wave + ((st + 1) >> 1) * 32, n_wave + ((st + 1) & 1) * 64, lane, nxt);
+            part += tail_stripe_full<EPI, CBF16>(g, s, blk4 + q * (32 * EPI_LD), m_wave + (st >> 1) * 32, n_wave + (st & 1) * 64, lane, cur, idt,
+                                                 has_in);
+#pragma unroll
+            for (int it = 0; it < T::NIT; ++it) { cur[it][0] = nxt[it][0]; cur[it][1] = nxt[it][1]; }
+        }
         __builtin_amdgcn_wave_barrier();
     }
     return part;
@@ -1552,7 +1661,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
         const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (OTTER_DIAG & (4 | 16)) == 0 &&
                           (g.cdt == OTTER_F32 || g.wide);
         if (full) {
-            float* blk2 = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_LD);
+            float* blk2 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
             if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
             else part = tail_wave_full<EPI, false>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
         } else {
@@ -1932,7 +2041,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
         const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (OTTER_DIAG & (4 | 16)) == 0 &&
                           (g.cdt == OTTER_F32 || g.wide);
         if (full) {
-            float* blk2 = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_LD);
+            float* blk2 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
             if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
             else part = tail_wave_full<EPI, false>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
         } else {
@@ -2175,7 +2284,7 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         return OTTER_OK;
     }
     if (cfg == CFG_R4 || cfg == CFG_R4B || cfg == CFG_R4C) {
-        const int smem = 2 * 65536;  // two K-tile buffers; the epilogue stripes alias the first
+        const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;  // two K-tile buffers; the tail's parking buffers alias them
         unsigned pg = grid.x < 256u ? grid.x : 256u;
 #define LAUNCH_R4(SCH_)                                                                                                    \
     do {                                                                                                                   \
@@ -2191,7 +2300,7 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     if (cfg == CFG_Q4) {
         static bool once = false;
-        const int smem = 4 * 32768 + 4096;  // ring; the epilogue stripes (4 x 32 x EPI_LD floats = 34816 B) alias its head
+        const int smem = TAIL_LDS_BYTES;  // 4 x 32 KB ring; the tail's parking buffers (139264 B) alias it
         if (!once) { int rc = set_smem(gemm_bf16_q4_kernel<EPI>, smem); if (rc) return rc; once = true; }
         unsigned pg = grid.x < 256u ? grid.x : 256u;
         hipLaunchKernelGGL((gemm_bf16_q4_kernel<EPI>), dim3(pg), dim3(256), smem, st, g);
