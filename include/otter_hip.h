@@ -92,6 +92,17 @@ int otter_rmsnorm_fwd(const void* x, int x_dtype, const void* w, int w_dtype, vo
 int otter_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd,
                       void* dx, float* dw, int accumulate, void* ws, int64_t rows, int64_t D, void* stream);
 
+/* LLaMA host (config C4) forms of the two above.  otter_add_rmsnorm_fwd: optional fused residual add (xsum = x + delta, both
+ * NULL for a plain norm) and an output dtype of its own (y = bf16 of the fp32 result: what autocast feeds the next Linear,
+ * rounded once).  Replaces `hidden = residual + hidden; hidden = post_attention_layernorm(hidden)` of the decoder layer
+ * (/root/reference/xformers_model/llama.py:311-318) in one pass over the residual stream.  otter_rmsnorm_bwd_ex: dy in its
+ * own dtype, optional dres added to dx, optional bf16 copy of dx, dw optional (NULL for the frozen decoder). */
+int otter_add_rmsnorm_fwd(const void* x, int x_dtype, const void* delta, int delta_dtype, void* xsum, const void* w, int w_dtype,
+                          void* y, int y_dtype, float* rstd, int64_t rows, int64_t D, float eps, void* stream);
+int otter_rmsnorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd,
+                         const void* dres, void* dx, int dx_dtype, void* dx_bf16, float* dw, int accumulate, void* ws, int64_t rows,
+                         int64_t D, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = epilogue( A[M,K] . B[N,K]^T )  -- both operands K-contiguous ("NT": exactly nn.Linear).
  * Replaces every bias-free nn.Linear on the path (modeling_otter.py:139-141,145,147,255-257,366,368) with the
@@ -223,6 +234,18 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream);
  * ------------------------------------------------------------------------------------------------------- */
 int otter_rope(const void* x, void* y, const float* cos_t, const float* sin_t, int64_t B, int64_t S, int64_t H,
                int64_t d, int64_t rot_dim, int inverse, int dtype, void* stream);
+
+/* Same rotation, bf16, full rotary, 16-byte vectors, on STRIDED tokens: `tokens` = B*S tokens whose H rotated heads are
+ * contiguous (head stride d) and which are x_token_stride / y_token_stride elements apart -- q and k inside the fused
+ * [B,S,3,H,d] projection buffer are H' = 2H heads with token stride 3*H*d.  In place allowed (y == x, equal strides). */
+int otter_rope_strided(const void* x, void* y, const float* cos_t, const float* sin_t, int64_t tokens, int64_t S, int64_t H,
+                       int64_t d, int inverse, int64_t x_token_stride, int64_t y_token_stride, void* stream);
+
+/* SwiGLU of the LLaMA MLP (/root/reference/xformers_model/llama.py:216-223: down(act(gate(x)) * up(x)), act = SiLU) on the
+ * [rows, 2*I] bf16 output of the concatenated gate|up projection: h[rows, I] = silu(g) * u;  backward writes
+ * dgate_up[rows, 2*I] = (dh * u * silu'(g) | dh * silu(g)). */
+int otter_swiglu_fwd(const void* gate_up, void* h, int64_t rows, int64_t I, void* stream);
+int otter_swiglu_bwd(const void* gate_up, const void* dh, void* dgate_up, int64_t rows, int64_t I, void* stream);
 
 /* x[i] += y[i] for a broadcast row block:  x [groups, rows, D] += emb [rows_e .. broadcast]; used for
  * frame_embs (modeling_otter.py:224-226).  x viewed as [outer, F, inner, D]; emb [F, D] fp32 master. */

@@ -71,6 +71,8 @@ SIGNATURES = {
     "otter_colsum": (_int, [_vp, _int, RowMap, _vp, _int, _vp, _i64, _i64, _vp]),
     "otter_rmsnorm_fwd": (_int, [_vp, _int, _vp, _int, _vp, _vp, _i64, _i64, _f32, _vp]),
     "otter_rmsnorm_bwd": (_int, [_vp, _vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _i64, _i64, _vp]),
+    "otter_add_rmsnorm_fwd": (_int, [_vp, _int, _vp, _int, _vp, _vp, _int, _vp, _int, _vp, _i64, _i64, _f32, _vp]),
+    "otter_rmsnorm_bwd_ex": (_int, [_vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _i64, _i64, _vp]),
     "otter_gemm_num_partials": (_i64, [_i64, _i64, _int]),
     "otter_gemm_nt": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _int, C.POINTER(EpilogueArgs), _vp]),
     "otter_gemm_set_variant": (_int, [_int]),
@@ -87,6 +89,9 @@ SIGNATURES = {
     "otter_attn_bwd": (_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64,
                               _i64, _i64, _i64, _int, _f32, _int, _vp]),
     "otter_rope": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
+    "otter_rope_strided": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _i64, _i64, _vp]),
+    "otter_swiglu_fwd": (_int, [_vp, _vp, _i64, _i64, _vp]),
+    "otter_swiglu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "otter_add_frame_embs": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _i64, _vp]),
     "otter_add_rows": (_int, [_vp, _vp, RowMap, _i64, _i64, _int, _vp]),
     "otter_flash_attn_fwd": (_int, [C.POINTER(FlashDesc), _vp]),

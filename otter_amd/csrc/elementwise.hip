@@ -120,6 +120,75 @@ __global__ void rope_kernel(const T* __restrict__ x, T* __restrict__ y, const fl
     }
 }
 
+// Vectorised, strided RoPE for the fused q/k/v projection buffer of the LLaMA host (config C4): a token's H rotated heads
+// are contiguous (head stride d), tokens are x_tok / y_tok elements apart (3*H*d inside a [B,S,3,H,d] buffer, H*d in a
+// packed one), full rotary (rot == d), bf16.  One lane owns 8 consecutive elements of the first half AND their 8 partners
+// in the second half: two 16-byte loads, two 16-byte stores, cos/sin rows read as fp32 vectors (L2-resident tables).
+__global__ void rope_vec_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ cs,
+                                const float* __restrict__ sn, int64_t S, int64_t H, int d, int inverse, int64_t x_tok, int64_t y_tok,
+                                int64_t total) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int half = d / 2, per_head = half / 8;
+    const int c = (int)(t % per_head);
+    const int64_t th = t / per_head;
+    const int64_t h = th % H, tok = th / H;
+    const int64_t s = tok % S;
+    const bf16_t* xp = x + tok * x_tok + h * d + 8 * c;
+    bf16_t* yp = y + tok * y_tok + h * d + 8 * c;
+    float x1[8], x2[8], o1[8], o2[8];
+    Vec8<bf16_t>::load(xp, x1);
+    Vec8<bf16_t>::load(xp + half, x2);
+    const float* c1 = cs + s * d + 8 * c;
+    const float* s1 = sn + s * d + 8 * c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (!inverse) {
+            o1[i] = x1[i] * c1[i] - x2[i] * s1[i];
+            o2[i] = x2[i] * c1[i + half] + x1[i] * s1[i + half];
+        } else {
+            o1[i] = x1[i] * c1[i] + x2[i] * s1[i + half];
+            o2[i] = x2[i] * c1[i + half] - x1[i] * s1[i];
+        }
+    }
+    Vec8<bf16_t>::store(yp, o1);
+    Vec8<bf16_t>::store(yp + half, o2);
+}
+
+// SwiGLU of the LLaMA MLP (xformers_model/llama.py:216-223 / HF LlamaMLP: down(silu(gate(x)) * up(x))) on the fused
+// [rows, 2*I] output of the concatenated gate|up projection: h = silu(g) * u (bf16, fp32 arithmetic), and its backward
+// dg = dh * u * silu'(g), du = dh * silu(g) written side by side into a [rows, 2*I] buffer (the dgrad GEMM operand).
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, int64_t I, int64_t nchunks) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const int64_t per_row = I / 8, row = t / per_row, c = t % per_row;
+    float g[8], u[8], o[8];
+    Vec8<bf16_t>::load(gu + row * 2 * I + 8 * c, g);
+    Vec8<bf16_t>::load(gu + row * 2 * I + I + 8 * c, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = g[i] / (1.0f + __expf(-g[i])) * u[i];
+    Vec8<bf16_t>::store(h + row * I + 8 * c, o);
+}
+__global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dh, bf16_t* __restrict__ dgu, int64_t I,
+                                  int64_t nchunks) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nchunks) return;
+    const int64_t per_row = I / 8, row = t / per_row, c = t % per_row;
+    float g[8], u[8], d[8], dg[8], du[8];
+    Vec8<bf16_t>::load(gu + row * 2 * I + 8 * c, g);
+    Vec8<bf16_t>::load(gu + row * 2 * I + I + 8 * c, u);
+    Vec8<bf16_t>::load(dh + row * I + 8 * c, d);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float sg = 1.0f / (1.0f + __expf(-g[i]));
+        const float silu = g[i] * sg;
+        du[i] = d[i] * silu;
+        dg[i] = d[i] * u[i] * (sg + silu * (1.0f - sg));   // silu'(g) = sg * (1 + g * (1 - sg))
+    }
+    Vec8<bf16_t>::store(dgu + row * 2 * I + 8 * c, dg);
+    Vec8<bf16_t>::store(dgu + row * 2 * I + I + 8 * c, du);
+}
+
 template <typename T>
 __global__ void add_frame_embs_kernel(T* __restrict__ x, const float* __restrict__ emb, int64_t F, int64_t inner, int64_t D,
                                       int64_t nchunks) {
@@ -219,6 +288,36 @@ int otter_rope(const void* x, void* y, const float* cos_t, const float* sin_t, i
         hipLaunchKernelGGL((rope_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, cos_t, sin_t, S, H,
                            (int)d, (int)rot_dim, inverse, total);
     OTTER_CHECK_LAUNCH("rope");
+    return OTTER_OK;
+}
+
+int otter_rope_strided(const void* x, void* y, const float* cos_t, const float* sin_t, int64_t tokens, int64_t S, int64_t H, int64_t d,
+                       int inverse, int64_t x_token_stride, int64_t y_token_stride, void* stream) {
+    OTTER_REQUIRE(x && y && cos_t && sin_t && tokens > 0 && S > 0 && H > 0, "rope_strided: bad args");
+    OTTER_REQUIRE(d % 16 == 0 && x_token_stride % 8 == 0 && y_token_stride % 8 == 0 && x_token_stride >= H * d && y_token_stride >= H * d,
+                  "rope_strided: head dim %ld must be a multiple of 16, token strides multiples of 8 and >= H*d", (long)d);
+    OTTER_REQUIRE((((uintptr_t)x) | ((uintptr_t)y)) % 16 == 0, "rope_strided: 16-byte alignment");
+    const int64_t total = tokens * H * (d / 16);
+    hipLaunchKernelGGL(rope_vec_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y,
+                       cos_t, sin_t, S, H, (int)d, inverse, x_token_stride, y_token_stride, total);
+    OTTER_CHECK_LAUNCH("rope_strided");
+    return OTTER_OK;
+}
+
+int otter_swiglu_fwd(const void* gate_up, void* h, int64_t rows, int64_t I, void* stream) {
+    OTTER_REQUIRE(gate_up && h && rows > 0 && I > 0 && I % 8 == 0, "swiglu_fwd: bad args (I %% 8)");
+    const int64_t n = rows * (I / 8);
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gate_up, (bf16_t*)h, I, n);
+    OTTER_CHECK_LAUNCH("swiglu_fwd");
+    return OTTER_OK;
+}
+
+int otter_swiglu_bwd(const void* gate_up, const void* dh, void* dgate_up, int64_t rows, int64_t I, void* stream) {
+    OTTER_REQUIRE(gate_up && dh && dgate_up && rows > 0 && I > 0 && I % 8 == 0, "swiglu_bwd: bad args (I %% 8)");
+    const int64_t n = rows * (I / 8);
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gate_up,
+                       (const bf16_t*)dh, (bf16_t*)dgate_up, I, n);
+    OTTER_CHECK_LAUNCH("swiglu_bwd");
     return OTTER_OK;
 }
 

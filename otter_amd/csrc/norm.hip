@@ -350,6 +350,23 @@ int otter_rmsnorm_fwd(const void* x, int x_dtype, const void* w, int w_dtype, vo
                             (hipStream_t)stream);
 }
 
+int otter_add_rmsnorm_fwd(const void* x, int x_dtype, const void* delta, int delta_dtype, void* xsum, const void* w, int w_dtype, void* y,
+                          int y_dtype, float* rstd, int64_t rows, int64_t D, float eps, void* stream) {
+    OTTER_REQUIRE((delta == nullptr) == (xsum == nullptr), "add_rmsnorm_fwd: delta and xsum go together");
+    otter_rowmap id = {0, 0, 0};
+    return launch_fwd<true>(x, x_dtype, w, nullptr, w_dtype, y, y_dtype, id, nullptr, nullptr, rstd, rows, D, eps, (hipStream_t)stream,
+                            delta, delta_dtype, xsum);
+}
+
+int otter_rmsnorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd,
+                         const void* dres, void* dx, int dx_dtype, void* dx_bf16, float* dw, int accumulate, void* ws, int64_t rows,
+                         int64_t D, void* stream) {
+    OTTER_REQUIRE(!dx_bf16 || dx, "rmsnorm_bwd_ex: dx_bf16 without dx");
+    otter_rowmap id = {0, 0, 0};
+    return launch_bwd<true>(dy, dy_dtype, id, x, x_dtype, w, w_dtype, nullptr, rstd, dres, dx, dx_dtype, (bf16_t*)dx_bf16, dw, nullptr,
+                            accumulate, ws, rows, D, (hipStream_t)stream);
+}
+
 int otter_rmsnorm_bwd(const void* dy, const void* x, int x_dtype, const void* w, int w_dtype, const float* rstd, void* dx,
                       float* dw, int accumulate, void* ws, int64_t rows, int64_t D, void* stream) {
     otter_rowmap id = {0, 0, 0};

@@ -204,6 +204,117 @@ def rms_norm(x, weight, eps=1e-6):
     return RMSNormFn.apply(x, weight, eps)
 
 
+class AddRMSNormFn(torch.autograd.Function):
+    """LLaMA host (config C4): y = RMSNorm(x [+ delta]) with its own output dtype, the residual add fused into the same pass
+    (xformers_model/llama.py:95-112 and the `residual + hidden_states` of :311-318).  Returns (xsum, y); xsum is x itself when
+    there is no delta.  Backward: one pass producing d(x) (+ the incoming d(xsum)) and, for a bf16 branch, its bf16 copy."""
+
+    @staticmethod
+    def forward(ctx, x, delta, weight, eps, out_dtype):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        d2 = delta.reshape(-1, shp[-1]).contiguous() if delta is not None else None
+        xsum, y, rstd = ops.add_rmsnorm_fwd(x2, d2, weight.detach(), out_dtype, eps)
+        xs = xsum if xsum is not None else x2
+        ctx.save_for_backward(xs, weight, rstd)
+        ctx.shp = shp
+        ctx.has_delta = delta is not None
+        ctx.ddtype = delta.dtype if delta is not None else None
+        if delta is None:
+            return y.view(shp)          # (an input must not be handed back as an output: no xsum without a delta)
+        return xsum.view(shp), y.view(shp)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        d_xsum, dy = grads if ctx.has_delta else (None, grads[0])
+        xs, weight, rstd = ctx.saved_tensors
+        D = ctx.shp[-1]
+        need_dw = weight.requires_grad
+        dres = d_xsum.reshape(-1, D).contiguous() if d_xsum is not None else None
+        if dres is not None and dres.dtype != xs.dtype:
+            dres = dres.to(xs.dtype)
+        dy2 = dy.reshape(-1, D).contiguous()
+        fused = ctx.has_delta and ctx.needs_input_grad[1] and ctx.ddtype == torch.bfloat16 and xs.dtype != torch.bfloat16
+        ddelta = torch.empty(xs.shape, dtype=torch.bfloat16, device=xs.device) if fused else None
+        dx, dw = ops.rmsnorm_bwd_ex(dy2, xs, weight.detach(), rstd, xs.dtype, dres=dres, need_dw=need_dw, dx_bf16=ddelta)
+        if ctx.has_delta and ctx.needs_input_grad[1] and not fused:
+            ddelta = dx if ctx.ddtype == dx.dtype else ops.cast(dx, ctx.ddtype)
+        return (dx.view(ctx.shp), ddelta.view(ctx.shp) if ddelta is not None else None,
+                dw.to(weight.dtype) if dw is not None else None, None, None)
+
+
+def add_rms_norm(x, delta, weight, eps=1e-6, out_dtype=None):
+    """y (delta is None) or (x + delta, y)."""
+    return AddRMSNormFn.apply(x, delta, weight, eps, out_dtype or x.dtype)
+
+
+class SwiGLUFn(torch.autograd.Function):
+    """h = silu(gate) * up on the fused [.., 2*I] gate|up projection output (xformers_model/llama.py:216-223), bf16."""
+
+    @staticmethod
+    def forward(ctx, gu):
+        shp = gu.shape
+        gu2 = gu.reshape(-1, shp[-1]).contiguous()
+        ctx.save_for_backward(gu2)
+        ctx.shp = shp
+        return ops.swiglu_fwd(gu2).view(shp[:-1] + (shp[-1] // 2,))
+
+    @staticmethod
+    def backward(ctx, dh):
+        (gu2,) = ctx.saved_tensors
+        dh2 = dh.reshape(-1, ctx.shp[-1] // 2)
+        dh2 = dh2.contiguous() if dh2.dtype == torch.bfloat16 else dh2.to(torch.bfloat16).contiguous()
+        return ops.swiglu_bwd(gu2, dh2).view(ctx.shp)
+
+
+def swiglu(gu):
+    return SwiGLUFn.apply(gu)
+
+
+class RopeFlashAttentionFn(torch.autograd.Function):
+    """LLaMA self-attention core on the fused q|k|v projection output [B,S,3*H*128] (bf16): RoPE on the q and k heads
+    (xformers_model/llama.py:158-166) written to a packed [B,S,2,H,128] buffer by one strided pass, then the causal /
+    key-padded flash attention of csrc/flash.hip (no ALiBi) with v read in place from the projection buffer.  Backward:
+    dq / dk / dv land in the three slices of ONE [B,S,3*H*128] buffer and the inverse rotation runs in place on its q|k part --
+    the buffer is then the operand of the (frozen) projection's dgrad GEMM.  Outputs: ctx [B,S,H*128], rotated k and v views
+    ([B,S,H,128], for the KV cache; not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, key_valid, n_heads, scale):
+        B, S, D3 = qkv.shape
+        H, d = n_heads, 128
+        qkv = qkv.contiguous()
+        qk = torch.empty((B, S, 2, H, d), dtype=torch.bfloat16, device=qkv.device)
+        ops.rope_strided(qkv, qk, cos, sin, B * S, S, 2 * H, d, 3 * H * d, 2 * H * d)
+        v5 = qkv.view(B, S, 3, H, d)
+        o, lse = ops.flash_attn_fwd(qk[:, :, 0], qk[:, :, 1], v5[:, :, 2], None, key_valid, scale, True)
+        ctx.save_for_backward(qk, qkv, o, lse, cos, sin, key_valid)
+        ctx.cfg = (H, scale)
+        k_rot, v = qk[:, :, 1], v5[:, :, 2]
+        ctx.mark_non_differentiable(k_rot, v)
+        return o.view(B, S, H * d), k_rot, v
+
+    @staticmethod
+    def backward(ctx, dout, _dk, _dv):
+        qk, qkv, o, lse, cos, sin, key_valid = ctx.saved_tensors
+        H, scale = ctx.cfg
+        B, S, _ = qkv.shape
+        d = 128
+        v5 = qkv.view(B, S, 3, H, d)
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(B, S, 3, H, d)
+        dout = dout.to(torch.bfloat16).contiguous().view(B, S, H, d)
+        ops.flash_attn_bwd(qk[:, :, 0], qk[:, :, 1], v5[:, :, 2], o, lse, dout, d5[:, :, 0], d5[:, :, 1], d5[:, :, 2], None, key_valid,
+                           scale, True)
+        ops.rope_strided(dqkv, dqkv, cos, sin, B * S, S, 2 * H, d, 3 * H * d, 3 * H * d, inverse=True)
+        return dqkv, None, None, None, None, None
+
+
+def rope_flash_attention(qkv, cos, sin, key_valid, n_heads, scale, want_kv=False):
+    ctx, k_rot, v = RopeFlashAttentionFn.apply(qkv, cos.contiguous(), sin.contiguous(), key_valid, n_heads, scale)
+    return ctx, (k_rot if want_kv else None), (v if want_kv else None)
+
+
 def layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
     return LayerNormFn.apply(x, weight, bias, eps, out_dtype or x.dtype)
 

@@ -11,6 +11,7 @@ OtterGatedCrossAttentionBlock :343-395, OtterLayer :398-442, OtterLMMixin :445-5
 """
 from __future__ import annotations
 
+import os
 import random
 import warnings
 from typing import List, Optional
@@ -396,11 +397,16 @@ class OtterForConditionalGeneration(OtterPreTrainedModel):
             text_tokenizer = _load_tokenizer("mosaicml/mpt-7b-instruct", tc.vocab_size)
             lang_encoder = MPTForCausalLM(tc)
         elif arch == "LlamaForCausalLM":
-            from transformers import LlamaForCausalLM
+            if os.environ.get("OTTER_HF_LLAMA") == "1":   # A/B switch: the third-party class the reference uses, HIP RMSNorm only
+                from transformers import LlamaForCausalLM
 
+                lang_encoder = LlamaForCausalLM(tc)
+                _use_hip_rmsnorm(lang_encoder)
+            else:
+                from .llama import LlamaForCausalLM       # MI355X-native host with the same class surface and state-dict keys
+
+                lang_encoder = LlamaForCausalLM(tc)
             text_tokenizer = _load_tokenizer(getattr(tc, "_name_or_path", "") or "llama", tc.vocab_size)
-            lang_encoder = LlamaForCausalLM(tc)
-            _use_hip_rmsnorm(lang_encoder)
         else:
             raise NotImplementedError(arch)
         vision_encoder = CLIPVisionModel(config.vision_config)

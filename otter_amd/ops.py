@@ -145,6 +145,37 @@ def rmsnorm_bwd(dy, x2d, w, rstd):
     return dx, dw
 
 
+def add_rmsnorm_fwd(x2d, delta2d, w, out_dtype, eps=1e-6):
+    """LLaMA host: (xsum, y, rstd) with xsum = x + delta (x's dtype; None when delta is None) and y = RMSNorm(xsum) in
+    `out_dtype` (bf16 of the fp32 result when the stream is fp32)."""
+    K.require_cuda(x2d, delta2d, w)
+    assert x2d.is_contiguous() and (delta2d is None or (delta2d.is_contiguous() and delta2d.shape == x2d.shape))
+    rows, D = x2d.shape
+    xsum = torch.empty_like(x2d) if delta2d is not None else None
+    y = torch.empty((rows, D), dtype=out_dtype, device=x2d.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    K.check(K.lib().otter_add_rmsnorm_fwd(x2d.data_ptr(), K.dt(x2d), K.ptr(delta2d), K.dt(delta2d) if delta2d is not None else F32, K.ptr(xsum),
+                                          w.data_ptr(), K.dt(w), y.data_ptr(), K.dt(y), rstd.data_ptr(), rows, D, float(eps), K.stream()),
+            "add_rmsnorm_fwd")
+    return xsum, y, rstd
+
+
+def rmsnorm_bwd_ex(dy, x2d, w, rstd, dx_dtype, dres=None, need_dw=False, dx_bf16=None):
+    """(dx, dw): dx = RMSNorm'(dy) (+ dres), optional bf16 copy of dx into dx_bf16, dw fp32 [D] only when need_dw."""
+    K.require_cuda(dy, x2d, w, rstd, dres, dx_bf16)
+    rows, D = x2d.shape
+    dev = x2d.device
+    assert dy.is_contiguous() and tuple(dy.shape) == (rows, D)
+    if dres is not None and (dres.dtype != dx_dtype or not dres.is_contiguous()):
+        raise K.OtterHipError("rmsnorm_bwd_ex: dres must be contiguous and have the dx dtype")
+    dx = torch.empty((rows, D), dtype=dx_dtype, device=dev)
+    dw = torch.empty(D, dtype=torch.float32, device=dev) if need_dw else None
+    ws = _ws.get(K.lib().otter_layernorm_bwd_workspace_bytes(rows, D), dev) if need_dw else None
+    K.check(K.lib().otter_rmsnorm_bwd_ex(dy.data_ptr(), K.dt(dy), x2d.data_ptr(), K.dt(x2d), w.data_ptr(), K.dt(w), rstd.data_ptr(), K.ptr(dres),
+                                         dx.data_ptr(), K.dt(dx), K.ptr(dx_bf16), K.ptr(dw), 0, K.ptr(ws), rows, D, K.stream()), "rmsnorm_bwd_ex")
+    return dx, dw
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------------------------------------------------
@@ -343,6 +374,40 @@ def rope(x, cos, sin, rot_dim=None, inverse=False, out=None):
     K.check(K.lib().otter_rope(x.data_ptr(), y.data_ptr(), cos.data_ptr(), sin.data_ptr(), B, S, H, d, rot, 1 if inverse else 0,
                                K.dt(x), K.stream()), "rope")
     return y
+
+
+def rope_strided(x, y, cos, sin, tokens, S, H, d, x_token_stride, y_token_stride, inverse=False):
+    """bf16 full-rotary RoPE on `tokens` = B*S tokens of H contiguous heads each, tokens x_/y_token_stride elements apart
+    (x / y are any tensors whose data_ptr is the first rotated element; in place when y is x).  cos/sin fp32 [S, d]."""
+    K.require_cuda(x, y, cos, sin)
+    if x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16 or cos.dtype != torch.float32 or sin.dtype != torch.float32:
+        raise K.OtterHipError("rope_strided: bf16 data, fp32 tables")
+    if not cos.is_contiguous() or not sin.is_contiguous() or tuple(cos.shape) != (S, d) or tuple(sin.shape) != (S, d):
+        raise K.OtterHipError("rope_strided: cos/sin must be contiguous [S, d]")
+    K.check(K.lib().otter_rope_strided(x.data_ptr(), y.data_ptr(), cos.data_ptr(), sin.data_ptr(), tokens, S, H, d, 1 if inverse else 0,
+                                       x_token_stride, y_token_stride, K.stream()), "rope_strided")
+    return y
+
+
+def swiglu_fwd(gu2d):
+    """gu2d [rows, 2*I] bf16 contiguous (gate | up) -> h [rows, I] = silu(gate) * up."""
+    K.require_cuda(gu2d)
+    rows, I2 = gu2d.shape
+    if gu2d.dtype != torch.bfloat16 or not gu2d.is_contiguous() or I2 % 16:
+        raise K.OtterHipError("swiglu: contiguous bf16 [rows, 2*I] with I % 8 == 0")
+    h = torch.empty((rows, I2 // 2), dtype=torch.bfloat16, device=gu2d.device)
+    K.check(K.lib().otter_swiglu_fwd(gu2d.data_ptr(), h.data_ptr(), rows, I2 // 2, K.stream()), "swiglu_fwd")
+    return h
+
+
+def swiglu_bwd(gu2d, dh2d):
+    K.require_cuda(gu2d, dh2d)
+    rows, I2 = gu2d.shape
+    if dh2d.dtype != torch.bfloat16 or not dh2d.is_contiguous() or tuple(dh2d.shape) != (rows, I2 // 2):
+        raise K.OtterHipError("swiglu_bwd: dh must be contiguous bf16 [rows, I]")
+    dgu = torch.empty_like(gu2d)
+    K.check(K.lib().otter_swiglu_bwd(gu2d.data_ptr(), dh2d.data_ptr(), dgu.data_ptr(), rows, I2 // 2, K.stream()), "swiglu_bwd")
+    return dgu
 
 
 def add_frame_embs_(x5, emb):

@@ -455,3 +455,75 @@ def _attention_core_case(ops, case, dt):
     tolb = 1e-4 if dt == "f32" else 2e-2
     assert relmax(host(dq), dq_ref) < tolb
     assert relmax(host(dkv[..., :inner]), dk_ref) < tolb and relmax(host(dkv[..., inner:]), dv_ref) < tolb
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LLaMA host kernels (config C4): fused add + RMSNorm with its own output dtype, strided RoPE, SwiGLU
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("with_delta", [False, True])
+def test_add_rmsnorm_fwd_bwd(ops, with_delta):
+    """fp32 residual stream, bf16 branch: y = bf16(w * x_norm) and the backward (dx + dres, bf16 copy, dw) against the oracle's
+    RMSNorm (xformers_model/llama.py:95-112) evaluated in fp32 on x + delta."""
+    r = rng(41)
+    rows, D = 70, 256
+    x = r.standard_normal((rows, D)).astype(np.float32)
+    delta = bf16_round(r.standard_normal((rows, D)) * 0.5) if with_delta else None
+    w = (1.0 + 0.1 * r.standard_normal(D)).astype(np.float32)
+    xs_ref = x + delta if with_delta else x
+    y_ref, cache = O.rms_norm_fwd(xs_ref, w)
+    xsum, y, rstd = ops.add_rmsnorm_fwd(to_dev(x), to_dev(delta, torch.bfloat16) if with_delta else None, to_dev(w), torch.bfloat16)
+    if with_delta:
+        assert relmax(host(xsum), xs_ref) < 1e-6
+    else:
+        assert xsum is None
+    assert relmax(host(y), y_ref) < 8e-3            # bf16 rounding of the output
+    dy = bf16_round(r.standard_normal((rows, D)))
+    dres = r.standard_normal((rows, D)).astype(np.float32)
+    dx_ref, dw_ref = O.rms_norm_bwd(dy.astype(np.float32), cache)
+    xs_dev = xsum if with_delta else to_dev(x)
+    dxb = torch.empty((rows, D), dtype=torch.bfloat16, device=DEV)
+    dx, dw = ops.rmsnorm_bwd_ex(to_dev(dy, torch.bfloat16), xs_dev, to_dev(w), rstd, torch.float32, dres=to_dev(dres), need_dw=True,
+                                dx_bf16=dxb)
+    assert relmax(host(dx), dx_ref + dres) < 1e-5
+    assert relmax(host(dxb), dx_ref + dres) < 8e-3
+    assert relmax(host(dw), dw_ref) < 1e-4
+    dx2, dw2 = ops.rmsnorm_bwd_ex(to_dev(dy, torch.bfloat16), xs_dev, to_dev(w), rstd, torch.float32)   # frozen decoder: no dw, no dres
+    assert dw2 is None and relmax(host(dx2), dx_ref) < 1e-5
+
+
+def test_rope_strided_qkv_buffer(ops):
+    """RoPE on the q and k heads inside a fused [B,S,3,H,128] projection buffer -> packed [B,S,2,H,128]; inverse in place.
+    Reference: oracle rope (xformers_model/llama.py:158-166) on the bf16 values, fp32 arithmetic."""
+    r = rng(43)
+    B, S, H, d = 2, 37, 3, 128
+    qkv = bf16_round(r.standard_normal((B, S, 3, H, d)))
+    cos, sin = O.rope_tables(S, d)
+    q_ref = O.rope_fwd(qkv[:, :, 0], cos, sin)
+    k_ref = O.rope_fwd(qkv[:, :, 1], cos, sin)
+    dq = to_dev(qkv, torch.bfloat16)
+    out = torch.zeros((B, S, 2, H, d), dtype=torch.bfloat16, device=DEV)
+    ops.rope_strided(dq, out, to_dev(cos), to_dev(sin), B * S, S, 2 * H, d, 3 * H * d, 2 * H * d)
+    assert relmax(host(out[:, :, 0]), q_ref) < 8e-3 and relmax(host(out[:, :, 1]), k_ref) < 8e-3
+    # in place + inverse on a gradient buffer: q|k parts rotated back, the v part untouched
+    g = bf16_round(r.standard_normal((B, S, 3, H, d)))
+    dg = to_dev(g, torch.bfloat16)
+    ops.rope_strided(dg, dg, to_dev(cos), to_dev(sin), B * S, S, 2 * H, d, 3 * H * d, 3 * H * d, inverse=True)
+    assert relmax(host(dg[:, :, 0]), O.rope_bwd(g[:, :, 0], cos, sin)) < 8e-3
+    assert relmax(host(dg[:, :, 1]), O.rope_bwd(g[:, :, 1], cos, sin)) < 8e-3
+    assert np.array_equal(host(dg[:, :, 2]), g[:, :, 2])
+
+
+def test_swiglu_fwd_bwd(ops):
+    r = rng(47)
+    rows, I = 53, 176
+    gu = bf16_round(r.standard_normal((rows, 2 * I)) * 2)
+    dh = bf16_round(r.standard_normal((rows, I)))
+    g, u = gu[:, :I].astype(np.float64), gu[:, I:].astype(np.float64)
+    sg = 1.0 / (1.0 + np.exp(-g))
+    h = ops.swiglu_fwd(to_dev(gu, torch.bfloat16))
+    assert relmax(host(h), g * sg * u) < 8e-3
+    dgu = ops.swiglu_bwd(to_dev(gu, torch.bfloat16), to_dev(dh, torch.bfloat16))
+    assert relmax(host(dgu[:, :I]), dh * u * (sg * (1 + g * (1 - sg)))) < 8e-3
+    assert relmax(host(dgu[:, I:]), dh * g * sg) < 8e-3
