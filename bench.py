@@ -37,19 +37,23 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; v
 MPT7B_TEXT = dict(architectures=["MPTForCausalLM"], d_model=4096, n_heads=32, n_layers=32, expansion_ratio=4, max_seq_len=2048,
                   vocab_size=50432, no_bias=True, norm_type="low_precision_layernorm", use_cache=False,
                   attn_config=dict(alibi=True, alibi_bias_max=8, attn_impl="torch", attn_type="multihead_attention"))
+LLAMA7B_TEXT = dict(architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                    num_attention_heads=32, num_key_value_heads=32, vocab_size=32004, max_position_embeddings=2048, rms_norm_eps=1e-6,
+                    tie_word_embeddings=False, hidden_act="silu", _name_or_path="llama-7b")   # 32000 + <|endofchunk|>, <image>, <answer>, <PAD>
 CLIP_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224,
                 patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=768)
 
 
-def build_model(device, seed=0, debug_layers=0):
+def build_model(device, seed=0, debug_layers=0, config="c2"):
     from otter_amd.configuration_otter import OtterConfig
     from otter_amd.modeling_otter import OtterForConditionalGeneration
 
-    text, vis = dict(MPT7B_TEXT), dict(CLIP_L14)
+    text, vis = dict(LLAMA7B_TEXT if config == "c4" else MPT7B_TEXT), dict(CLIP_L14)
     if debug_layers:
-        text["n_layers"] = debug_layers
+        text["num_hidden_layers" if config == "c4" else "n_layers"] = debug_layers
         vis["num_hidden_layers"] = 2
-    cfg = OtterConfig(vision_config=vis, text_config=text, cross_attn_every_n_layers=4)
+    extra = dict(max_num_frames=8) if config == "c4" else {}   # OTTER-Video: learned frame embeddings (modeling_otter.py:202-211)
+    cfg = OtterConfig(vision_config=vis, text_config=text, cross_attn_every_n_layers=4, **extra)
     torch.manual_seed(seed)
     with torch.device(device):
         model = OtterForConditionalGeneration(cfg)
@@ -69,14 +73,14 @@ def build_model(device, seed=0, debug_layers=0):
     return model
 
 
-def synth_batch(model, B, T, device, seed):
+def synth_batch(model, B, T, device, seed, frames=1):
     """SURVEY.md section 8d synthetic batch: BOS at 0, <image> at 1, one <answer> ... <|endofchunk|> span, labels by the
     reference's masking() rule."""
     from otter_amd.train import masking
 
     g = torch.Generator(device="cpu").manual_seed(seed)
-    vision_x = torch.randn(B, 1, 1, 3, 224, 224, generator=g).to(device)
-    ids = torch.randint(1, 50277, (B, T), generator=g)
+    vision_x = torch.randn(B, 1, frames, 3, 224, 224, generator=g).to(device)   # frames of one sample sit on the F axis (SURVEY 8d)
+    ids = torch.randint(1, min(50277, model.lang_encoder.config.vocab_size - 8), (B, T), generator=g)
     tok = model.text_tokenizer
     answer_id = tok.encode("<answer>")[-1]
     ids[:, 0] = 0
@@ -159,6 +163,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2 = OTTER-Image-MPT7B (BASELINE metric, the default); c4 = OTTER-Video-LLaMA7B, 8 frames per sample (configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--debug-layers", type=int, default=0, help="DEBUG ONLY: shrink MPT to this many layers (not a valid bench)")
@@ -184,11 +190,11 @@ def main():
 
     if args.gemm_variant:
         ops.set_gemm_variant(args.gemm_variant)
-    model = build_model(device, seed=0, debug_layers=args.debug_layers)  # identical replica on every rank (same seed)
+    model = build_model(device, seed=0, debug_layers=args.debug_layers, config=args.config)  # identical replica on every rank (same seed)
     step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16,
                      force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1")
     B, T = args.batch, args.seq
-    batch = synth_batch(model, B, T, device, seed=1000 + rank)
+    batch = synth_batch(model, B, T, device, seed=1000 + rank, frames=8 if args.config == "c4" else 1)
 
     def sync():
         torch.cuda.synchronize()
@@ -223,15 +229,18 @@ def main():
             # HBM-side traffic per launch comes from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
             # WRITE_SIZE) committed under profiles/; PMC collection cannot share a run with the timed region.
             traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm_ffn_v13.json")
+            v = args.gemm_variant or 18
+            names = {13: "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves, phased)", 18: "gemm_bf16_r4_kernel (256x256x64 tile, 4 waves, register-resident K-tile)"}
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_ffn_v18.json" if v == 18 else "r01_pmc_gemm_ffn_v13.json")
             if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
                 with open(pmc) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves) M=%d N=%d K=%d" % (M, N, Kd), "achieved": round(ach, 1),
+            roof = {"bound": "mfma", "kernel": "%s M=%d N=%d K=%d" % (names.get(v, "gemm variant %d" % v), M, N, Kd), "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
         out = {
-            "metric": "image-text pairs/s (train step) OTTER-MPT7B, 1 img+512 tok",
+            "metric": ("image-text pairs/s (train step) OTTER-MPT7B, 1 img+512 tok" if args.config == "c2"
+                       else "video-text pairs/s (train step) OTTER-Video-LLaMA7B, 8 frames+512 tok"),
             "value": round(pairs / elapsed, 3),
             "unit": "pairs/s",
             "n_gpus": world,
@@ -243,13 +252,16 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") + "OTTER-Image-MPT7B instruction-following train step, 1x224^2 image + %d tokens per pair, "
-                                   "batch %d per GPU (BASELINE configs[1]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B),
+            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") +
+                                   (("OTTER-Image-MPT7B instruction-following train step, 1x224^2 image + %d tokens per pair, "
+                                     "batch %d per GPU (BASELINE configs[1]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B)) if args.config == "c2" else
+                                    ("OTTER-Video-LLaMA7B-DenseCaption train step, 8x224^2 frames (T_img=1, F=8: 2048 patches) + %d tokens per pair, "
+                                     "batch %d per GPU (BASELINE configs[3]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B))),
                        "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
             "loss": round(float(loss), 4),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
             out["cpu_baseline"] = cpu_baseline(T)
         print(json.dumps(out), flush=True)
     if use_dist:
