@@ -512,42 +512,39 @@ class OtterForConditionalGeneration(OtterPreTrainedModel):
     @torch.no_grad()
     def generate(self, vision_x: torch.Tensor, lang_x: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                  **generate_kwargs):
-        """Greedy / sampling-free decoding with the reference's call contract (modeling_otter.py:999-1042): encodes the
-        vision input once, decodes with eos_token_id = <|endofchunk|>, clears the conditioning, returns lang_x with the new
-        tokens appended.  `use_cache` selects between the two decode modes of SURVEY.md section 3.2 (default: the LM
-        config's use_cache, False for OTTER-MPT7B).  Beam search / sampling are HF GenerationMixin features that the
-        pinned transformers provided; num_beams > 1 raises here."""
-        num_beams = generate_kwargs.pop("num_beams", 1)
-        if num_beams != 1 or generate_kwargs.pop("do_sample", False):
-            raise NotImplementedError("otter_amd.generate implements greedy decoding (num_beams=1, do_sample=False)")
-        max_new = generate_kwargs.pop("max_new_tokens", None)
-        max_length = generate_kwargs.pop("max_length", None)
-        if max_new is None:
-            max_new = (max_length - lang_x.shape[1]) if max_length is not None else 20
-        use_cache = generate_kwargs.pop("use_cache", getattr(self.lang_encoder.config, "use_cache", False))
-        eos = generate_kwargs.pop("eos_token_id", self.eoc_token_id)
-        pad = generate_kwargs.pop("pad_token_id", eos)
+        """The reference's call contract (modeling_otter.py:999-1042): encode the vision input once (every beam of a sample is
+        conditioned on that sample's media, the reference's `vision_x.repeat_interleave(num_beams)`), decode with
+        eos_token_id = <|endofchunk|> unless the caller overrides it, clear the conditioning, return lang_x with the new tokens
+        appended.  The decoding itself -- greedy, beam search with `no_repeat_ngram_size` / `bad_words_ids` /
+        `length_penalty` / `min_new_tokens`, temperature / top-k / top-p sampling: what the reference's demos, benchmark
+        wrappers and serving code pass -- is otter_amd/generation.py (the pinned transformers' algorithm, restated).
+        `use_cache` selects between the two decode modes of SURVEY.md section 3.2 (default: the LM config's use_cache, False
+        for OTTER-MPT7B)."""
+        from .generation import generate_tokens
+
+        num_beams = int(generate_kwargs.get("num_beams", 1) or 1)
+        use_cache = bool(generate_kwargs.pop("use_cache", getattr(self.lang_encoder.config, "use_cache", False)))
+        generate_kwargs.setdefault("eos_token_id", self.eoc_token_id)
         self._encode_vision_x(vision_x=vision_x)
-        ids = lang_x
-        mask = attention_mask
-        done = torch.zeros(ids.shape[0], dtype=torch.bool, device=ids.device)
-        past = None
-        for _ in range(max(int(max_new), 0)):
+        if num_beams > 1:   # perceiver output repeated per beam: same conditioning as encoding the repeated frames, 1/num_beams the work
+            for layer in self.lang_encoder._get_decoder_layers():
+                if layer.vis_x is not None:
+                    layer.condition_vis_x(layer.vis_x.repeat_interleave(num_beams, dim=0))
+        lm = self.lang_encoder
+
+        def step(ids, mask, past, beam_idx):
             if use_cache and past is not None:
-                out = self.lang_encoder(input_ids=ids[:, -1:], attention_mask=mask, past_key_values=past, use_cache=True)
+                if beam_idx is not None:
+                    past = tuple(tuple(t.index_select(0, beam_idx) for t in layer) for layer in past)
+                out = lm(input_ids=ids[:, -1:], attention_mask=mask, past_key_values=past, use_cache=True)
             else:
-                out = self.lang_encoder(input_ids=ids, attention_mask=mask, use_cache=bool(use_cache))
-            past = out.past_key_values if use_cache else None
-            nxt = out.logits[:, -1, :].float().argmax(-1)
-            nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
-            done = done | (nxt == eos)
-            ids = torch.cat([ids, nxt[:, None]], dim=1)
-            if mask is not None:
-                mask = torch.cat([mask, torch.ones_like(mask[:, :1])], dim=1)
-            if bool(done.all()):
-                break
-        self.lang_encoder.clear_conditioned_layers()
-        return ids
+                out = lm(input_ids=ids, attention_mask=mask, use_cache=use_cache)
+            return out.logits[:, -1, :], (out.past_key_values if use_cache else None)
+
+        try:
+            return generate_tokens(step, lang_x, attention_mask, **generate_kwargs)
+        finally:
+            self.lang_encoder.clear_conditioned_layers()
 
 
 class _nullctx:
