@@ -241,6 +241,10 @@ int otter_rope(const void* x, void* y, const float* cos_t, const float* sin_t, i
 int otter_rope_strided(const void* x, void* y, const float* cos_t, const float* sin_t, int64_t tokens, int64_t S, int64_t H,
                        int64_t d, int inverse, int64_t x_token_stride, int64_t y_token_stride, void* stream);
 
+/* quick-GELU of the frozen CLIP tower's MLP (/root/reference/xformers_model/clip.py:84-95: x * sigmoid(1.702 x)); bf16 or
+ * f32, n elements (multiple of 8), in place allowed. */
+int otter_quick_gelu(const void* x, void* y, int64_t n, int dtype, void* stream);
+
 /* SwiGLU of the LLaMA MLP (/root/reference/xformers_model/llama.py:216-223: down(act(gate(x)) * up(x)), act = SiLU) on the
  * [rows, 2*I] bf16 output of the concatenated gate|up projection: h[rows, I] = silu(g) * u;  backward writes
  * dgate_up[rows, 2*I] = (dh * u * silu'(g) | dh * silu(g)). */

@@ -90,6 +90,7 @@ SIGNATURES = {
                               _i64, _i64, _i64, _int, _f32, _int, _vp]),
     "otter_rope": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
     "otter_rope_strided": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _i64, _i64, _vp]),
+    "otter_quick_gelu": (_int, [_vp, _vp, _i64, _int, _vp]),
     "otter_swiglu_fwd": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "otter_swiglu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "otter_add_frame_embs": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _i64, _vp]),

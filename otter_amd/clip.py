@@ -2,12 +2,15 @@
 
 The reference instantiates transformers==4.35.1 `CLIPVisionModel` (modeling_otter.py:768,991; in-repo restatement at
 /root/reference/xformers_model/clip.py:50-199,393-446).  The tower is frozen and inference-only in the Otter recipe
-("next" tier), so round 1 keeps its GEMMs/attention on PyTorch-ROCm; this class exists to
-pin the *checkpoint contract*: state-dict keys are `vision_model.embeddings.*`, `vision_model.pre_layrnorm.*`,
+("next" tier).  Round 2: its no_grad inference path runs q|k|v as one GEMM, the attention core on
+the head_dim-64 MFMA kernels of csrc/attn_mfma.hip, quick-GELU and the residual-add + LayerNorm pairs as single HIP passes
+(`_forward_fused`); the GEMMs stay on hipBLASLt.  The class also pins the *checkpoint contract*: state-dict keys are `vision_model.embeddings.*`, `vision_model.pre_layrnorm.*`,
 `vision_model.encoder.layers.{i}.*`, `vision_model.post_layernorm.*` exactly as the pinned transformers version spells
 them (transformers 5.x renamed them, which would break every published Otter checkpoint).
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn as nn
@@ -124,10 +127,46 @@ class _VisionTransformer(nn.Module):
                 a = ops.layernorm_fwd(x2, n1.weight, n1.bias, cd, n1.eps, need_stats=False)[0]
             else:
                 x2, a, _, _ = ops.add_layernorm_fwd(x2, delta, n1.weight, n1.bias, cd, n1.eps, need_stats=False)
-            b = layer.self_attn(a.view(shp)).reshape(-1, shp[-1])
+            b = self._attn_fused(layer.self_attn, a, shp, cd)
             x2, m, _, _ = ops.add_layernorm_fwd(x2, b.contiguous(), n2.weight, n2.bias, cd, n2.eps, need_stats=False)
-            delta = layer.mlp(m.view(shp)).reshape(-1, shp[-1]).contiguous()
+            delta = self._mlp_fused(layer.mlp, m, cd)
         return (x2 + delta).view(shp)
+
+    @staticmethod
+    def _attn_fused(att, a2, shp, cd):
+        """q|k|v as ONE GEMM against the concatenated frozen weights and biases, then the HIP attention core (head_dim 64 MFMA
+        kernels of csrc/attn_mfma.hip, unmasked, 257 keys) reading q, k, v as strided views of that buffer: no chunk / transpose
+        copies, no torch SDPA."""
+        from . import ops
+        from ._capi import MASK_NONE
+
+        N, S, D = shp
+        H = att.num_heads
+        if D // H != 64 or cd != torch.bfloat16 or os.environ.get("OTTER_CLIP_SDPA") == "1":   # env: A/B switch back to torch SDPA
+            return att(a2.view(shp)).reshape(-1, D)
+        key = tuple((l.weight._version, l.weight.data_ptr(), l.bias._version) for l in (att.q_proj, att.k_proj, att.v_proj)) + (cd,)
+        if getattr(att, "_qkv_key", None) != key:
+            att._qkv_w = torch.cat([l.weight.detach().to(cd) for l in (att.q_proj, att.k_proj, att.v_proj)], 0).contiguous()
+            att._qkv_b = torch.cat([l.bias.detach().to(cd) for l in (att.q_proj, att.k_proj, att.v_proj)], 0).contiguous()
+            att._qkv_key = key
+        qkv = F.linear(a2.view(N, S, D), att._qkv_w, att._qkv_b)                   # [N, S, 3*D]
+        o, _ = ops.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], H, None, S, MASK_NONE, (D // H) ** -0.5, need_lse=False)
+        return F.linear(o, att.out_proj.weight.to(cd), att.out_proj.bias.to(cd)).reshape(-1, D)
+
+    @staticmethod
+    def _mlp_fused(mlp, m2, cd):
+        from . import ops
+
+        h = F.linear(m2, mlp.fc1.weight.to(cd), mlp.fc1.bias.to(cd))
+        if mlp.act == "quick_gelu" and h.is_contiguous() and h.numel() % 8 == 0:
+            ops.quick_gelu_(h)                                                       # one in-place HIP pass
+        elif mlp.act == "quick_gelu":
+            h = h * torch.sigmoid(1.702 * h)
+        elif mlp.act == "gelu":
+            h = F.gelu(h)
+        else:
+            raise NotImplementedError(mlp.act)
+        return F.linear(h, mlp.fc2.weight.to(cd), mlp.fc2.bias.to(cd)).contiguous()
 
 
 class CLIPVisionModel(nn.Module):

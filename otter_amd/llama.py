@@ -186,15 +186,23 @@ class LlamaDecoderLayer(nn.Module):
         self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, hidden_states, attention_mask=None, cos=None, sin=None, key_valid=None, past_key_value=None, use_cache=False,
-                flash=False, **unused):
+                flash=False, deferred=None, defer_out=False, **unused):
+        """`deferred` / `defer_out` (otter_amd extension, used by LlamaModel.forward): the MLP output of a layer is handed to
+        the NEXT layer un-added, where the residual add is fused into that layer's input RMSNorm pass (one trip over the fp32
+        residual stream instead of two).  With the defaults this is exactly the reference block."""
         x = hidden_states
         cd = OF.compute_dtype_for(x)
-        a = self.input_layernorm(x, out_dtype=cd)
+        if deferred is not None:
+            x, a = self.input_layernorm(x, delta=deferred, out_dtype=cd)       # x = x + mlp_out(prev) ; a = norm(x)
+        else:
+            a = self.input_layernorm(x, out_dtype=cd)
         b, new_past = self.self_attn(a, cos, sin, attn_mask=attention_mask, key_valid=key_valid, past_key_value=past_key_value,
                                      use_cache=use_cache, flash=flash)
         x, m = self.post_attention_layernorm(x, delta=b, out_dtype=cd)          # x = x + b ; m = norm(x)   (one pass)
-        x = x + self.mlp(m).to(x.dtype)
-        return x, new_past
+        d = self.mlp(m)
+        if defer_out:
+            return x, new_past, d
+        return x + d, new_past
 
 
 class LlamaPreTrainedModel(PreTrainedModel):
@@ -276,13 +284,22 @@ class LlamaModel(LlamaPreTrainedModel):
                 mask = mask.expand(B, -1, -1, -1).masked_fill(~am[:, None, None, -s_k:], neg)
             mask = mask.to(cd)
         new_pasts = [] if use_cache else None
+        # each layer hands its MLP output over un-added (`delta`); a wrapper that runs something on the hidden states before the
+        # decoder layer (OtterLayer with a gated cross-attention block) needs the materialised sum
+        delta = None
         for i, layer in enumerate(self.layers):
             pkv = past_key_values[i] if (past_key_values is not None and len(past_key_values) > i) else None
-            x, npkv = layer(x, attention_mask=mask, cos=cos, sin=sin, key_valid=key_valid, past_key_value=pkv, use_cache=use_cache,
-                            flash=flash)
+            if delta is not None and getattr(layer, "gated_cross_attn_layer", None) is not None:
+                x = x + delta
+                delta = None
+            x, npkv, delta = layer(x, attention_mask=mask, cos=cos, sin=sin, key_valid=key_valid, past_key_value=pkv, use_cache=use_cache,
+                                   flash=flash, deferred=delta, defer_out=True)
             if use_cache:
                 new_pasts.append(npkv)
-        x = self.norm(x, out_dtype=OF.compute_dtype_for(x))
+        if delta is not None:
+            _, x = self.norm(x, delta=delta, out_dtype=OF.compute_dtype_for(x))
+        else:
+            x = self.norm(x, out_dtype=OF.compute_dtype_for(x))
         return BaseModelOutputWithPast(last_hidden_state=x, past_key_values=tuple(new_pasts) if use_cache else None)
 
 

@@ -535,7 +535,7 @@ class OtterForConditionalGeneration(OtterPreTrainedModel):
         def step(ids, mask, past, beam_idx):
             if use_cache and past is not None:
                 if beam_idx is not None:
-                    past = tuple(tuple(t.index_select(0, beam_idx) for t in layer) for layer in past)
+                    past = [tuple(t.index_select(0, beam_idx) for t in layer) for layer in past]   # a list: the MPT host fills it in place
                 out = lm(input_ids=ids[:, -1:], attention_mask=mask, past_key_values=past, use_cache=True)
             else:
                 out = lm(input_ids=ids, attention_mask=mask, use_cache=use_cache)

@@ -299,6 +299,8 @@ class MPTModel(MPTPreTrainedModel):
             attn_bias = attn_bias.to(OF.compute_dtype_for(x))
         if use_cache and past_key_values is None:
             past_key_values = [() for _ in range(self.config.n_layers)]
+        elif past_key_values is not None and not isinstance(past_key_values, list):
+            past_key_values = list(past_key_values)   # filled in place below (the reference takes a list, modeling_mpt.py:290-292)
         # Each block hands its FFN output over un-added (`delta`); the add is fused into the next LayerNorm pass.  A wrapper
         # that runs something on the hidden states before the decoder layer (OtterLayer with a gated cross-attention block)
         # needs the materialised sum, so the add is performed here for those layers.

@@ -389,6 +389,15 @@ def rope_strided(x, y, cos, sin, tokens, S, H, d, x_token_stride, y_token_stride
     return y
 
 
+def quick_gelu_(x):
+    """In place x * sigmoid(1.702 x) on a contiguous bf16 / f32 tensor (CLIP MLP activation)."""
+    K.require_cuda(x)
+    if not x.is_contiguous() or x.numel() % 8:
+        raise K.OtterHipError("quick_gelu: contiguous tensor with numel % 8 == 0")
+    K.check(K.lib().otter_quick_gelu(x.data_ptr(), x.data_ptr(), x.numel(), K.dt(x), K.stream()), "quick_gelu")
+    return x
+
+
 def swiglu_fwd(gu2d):
     """gu2d [rows, 2*I] bf16 contiguous (gate | up) -> h [rows, I] = silu(gate) * up."""
     K.require_cuda(gu2d)

@@ -527,3 +527,27 @@ def test_swiglu_fwd_bwd(ops):
     dgu = ops.swiglu_bwd(to_dev(gu, torch.bfloat16), to_dev(dh, torch.bfloat16))
     assert relmax(host(dgu[:, :I]), dh * u * (sg * (1 + g * (1 - sg)))) < 8e-3
     assert relmax(host(dgu[:, I:]), dh * g * sg) < 8e-3
+
+
+def test_quick_gelu_and_clip_attention_core(ops):
+    """CLIP tower pieces on HIP: in-place quick-GELU, and the attention core on strided q/k/v views of one fused projection
+    buffer with CLIP's shape (16 heads x 64, 257 tokens, no mask) against an fp64 softmax attention."""
+    from otter_amd._capi import MASK_NONE
+
+    r = rng(51)
+    x = bf16_round(r.standard_normal((37, 4096)) * 3)
+    y = ops.quick_gelu_(to_dev(x, torch.bfloat16))
+    assert relmax(host(y), x / (1 + np.exp(-1.702 * x.astype(np.float64)))) < 8e-3
+    N, S, H, d = 3, 257, 16, 64
+    D = H * d
+    qkv = bf16_round(r.standard_normal((N, S, 3 * D)))
+    t = to_dev(qkv, torch.bfloat16)
+    o, _ = ops.attn_fwd(t[..., :D], t[..., D:2 * D], t[..., 2 * D:], H, None, S, MASK_NONE, d ** -0.5, need_lse=False)
+    q = qkv[..., :D].reshape(N, S, H, d).transpose(0, 2, 1, 3).astype(np.float64)
+    k = qkv[..., D:2 * D].reshape(N, S, H, d).transpose(0, 2, 1, 3).astype(np.float64)
+    v = qkv[..., 2 * D:].reshape(N, S, H, d).transpose(0, 2, 1, 3).astype(np.float64)
+    sc = q @ k.transpose(0, 1, 3, 2) * d ** -0.5
+    p = np.exp(sc - sc.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(N, S, D)
+    assert relmax(host(o), ref) < 1e-2
