@@ -40,6 +40,9 @@ MPT7B_TEXT = dict(architectures=["MPTForCausalLM"], d_model=4096, n_heads=32, n_
 LLAMA7B_TEXT = dict(architectures=["LlamaForCausalLM"], model_type="llama", hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
                     num_attention_heads=32, num_key_value_heads=32, vocab_size=32004, max_position_embeddings=2048, rms_norm_eps=1e-6,
                     tie_word_embeddings=False, hidden_act="silu", _name_or_path="llama-7b")   # 32000 + <|endofchunk|>, <image>, <answer>, <PAD>
+FUYU8B_TEXT = dict(model_type="persimmon", vocab_size=262144, hidden_size=4096, intermediate_size=16384, num_hidden_layers=36,
+                   num_attention_heads=64, max_position_embeddings=16384, qk_layernorm=True, partial_rotary_factor=0.5, hidden_act="relu2",
+                   layer_norm_eps=1e-5, rope_theta=25000.0, tie_word_embeddings=False)
 CLIP_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224,
                 patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=768)
 
@@ -71,6 +74,98 @@ def build_model(device, seed=0, debug_layers=0, config="c2"):
                 p.data = p.data.to(torch.bfloat16)
     model.train()
     return model
+
+
+def run_c5(args, device, rank, world, use_dist):
+    """Config C5 (BASELINE configs[4]): OtterHD = Fuyu-8B fully fine-tuned, one 1080x1080 image per sample as 36x36 linear patch tokens
+    (30x30x3 values each) + 36 newline tokens + a text tail; no vision tower, no gated cross-attention.  One step = forward + backward
+    (every parameter trains) + DP gradient average + clip + AdamW (otter_amd.optim.FusedAdamW)."""
+    from transformers import FuyuConfig
+
+    from otter_amd.dp import GradReducer
+    from otter_amd.fuyu import FuyuForCausalLM
+    from otter_amd.optim import FusedAdamW
+
+    text = dict(FUYU8B_TEXT)
+    if args.debug_layers:
+        text["num_hidden_layers"] = args.debug_layers
+    cfg = FuyuConfig(text_config=text, patch_size=30, num_channels=3, **{k: text[k] for k in ("vocab_size", "hidden_size", "intermediate_size",
+                     "num_hidden_layers", "num_attention_heads", "max_position_embeddings")})
+    torch.manual_seed(0)
+    with torch.device(device):
+        model = FuyuForCausalLM(cfg)
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.ndim >= 2:
+                p.normal_(0.0, 0.02, generator=g)
+    model.train()
+    params = [p for p in model.parameters()]
+    opt = FusedAdamW([{"params": [p for p in params if p.ndim >= 2], "weight_decay": 0.1}, {"params": [p for p in params if p.ndim < 2], "weight_decay": 0.0}],
+                     lr=1e-5, max_grad_norm=1.0)
+    reducer = GradReducer(params, 1 << 30) if use_dist else None
+    B, text_len = args.batch, 64
+    grid, P = 36, 36 * 36
+    S = grid * (grid + 1) + text_len                      # 1332 image positions (36 rows x (36 patches + newline)) + text
+    gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    patches = torch.randn(B, P, 2700, generator=gen).to(device)
+    ids = torch.randint(10, 262000, (B, S), generator=gen)
+    idx = torch.full((B, S), -1, dtype=torch.long)
+    for r in range(grid):
+        idx[:, r * (grid + 1): r * (grid + 1) + grid] = torch.arange(r * grid, (r + 1) * grid)
+    labels = ids.clone()
+    labels[:, : grid * (grid + 1) + 8] = -100             # the image and the instruction are not targets
+    ids, idx, labels = ids.to(device), idx.to(device), labels.to(device)
+
+    def step():
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(input_ids=ids, image_patches=patches.to(torch.bfloat16), image_patches_indices=idx, labels=labels).loss
+        loss.backward()
+        if reducer is not None:
+            reducer.wait()
+        opt.step()
+        return loss.detach()
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    if rank == 0:
+        n_par = sum(p.numel() for p in params)
+        flops = 6.0 * n_par * B * S + 12.0 * text["num_hidden_layers"] * B * S * S * 4096 * 0.5   # dense 6ND + causal attention fwd+bwd
+        print(json.dumps({
+            "metric": "image-text pairs/s (train step) OtterHD Fuyu-8B, 1080x1080 image as 1296 patch tokens + %d text tokens" % text_len,
+            "value": round(B * world * args.steps / elapsed, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") +
+                       "OtterHD / Fuyu-8B full fine-tune step (BASELINE configs[4]): %d pairs per GPU, sequence %d = 36x(36 patches + newline) + %d text, "
+                       "every parameter trainable (%.2f B), bf16 autocast, fp32 masters" % (B, S, text_len, n_par / 1e9),
+                       "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
+            "loss": round(float(loss), 4),
+            "model_tflops_per_s": round(flops * args.steps / elapsed / 1e12, 1)}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def synth_batch(model, B, T, device, seed, frames=1):
@@ -163,8 +258,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU (BASELINE configs[1]: 8)")
     ap.add_argument("--seq", type=int, default=512)
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
-                    help="c2 = OTTER-Image-MPT7B (BASELINE metric, the default); c4 = OTTER-Video-LLaMA7B, 8 frames per sample (configs[3])")
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
+                    help="c2 = OTTER-Image-MPT7B (BASELINE metric, the default); c4 = OTTER-Video-LLaMA7B, 8 frames per sample (configs[3]); "
+                         "c5 = OtterHD / Fuyu-8B full fine-tune, 1080x1080 patch tokens (configs[4]; default batch 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--debug-layers", type=int, default=0, help="DEBUG ONLY: shrink MPT to this many layers (not a valid bench)")
@@ -184,6 +280,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if args.config == "c5":
+        if args.batch == 8 and "--batch" not in sys.argv:
+            args.batch = 4
+        return run_c5(args, device, rank, world, use_dist)
 
     from otter_amd import ops
     from otter_amd.train import TrainStep

@@ -262,6 +262,31 @@ int otter_add_frame_embs(void* x, int x_dtype, const float* emb, int64_t outer, 
 int otter_add_rows(void* dst, const void* src, otter_rowmap src_map, int64_t rows, int64_t D, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * OtterHD / Fuyu-8B path (config C5): row-wise kernels of the Persimmon decoder and the patch scatter.
+ *   otter_qk_norm_rope_fwd  /root/reference/src/otter_ai/models/fuyu/modeling_persimmon.py:262-304: the per-head interleaved
+ *       projection output qkv [tokens, H, 3, 64] (bf16) is read in place; q and k get LayerNorm over the 64-wide head
+ *       (gamma / beta fp32 [64]) and the partial rotary embedding on their first `rot` dims (cos / sin fp32 [S, rot], position
+ *       = token % S); q', k', v are written as bf16 [tokens, H, 128] with columns 64..127 zero (head-dim padding for the
+ *       128-wide flash kernels).  stats [tokens, H, 2, 2] fp32 = (mean, rstd) of q and k, for the backward.
+ *   otter_qk_norm_rope_bwd  dq / dk / dv [tokens, H, 128] (columns 0..63 used) -> dqkv [tokens, H, 3, 64]; partial
+ *       [otter_qk_norm_rope_bwd_blocks(tokens, H), 4, 64] fp32 = per-block sums of (dgamma_q, dbeta_q, dgamma_k, dbeta_k),
+ *       to be summed over the first axis by the caller (deterministic).
+ *   otter_sqrelu_fwd/_bwd   relu(x)^2 (:180-194), bf16, n % 8 == 0.
+ *   otter_scatter_rows      fuyu/modeling_fuyu.py:44-77: out[b,s,:] = idx[b,s] < 0 ? word[b,s,:] : patch[b, idx[b,s], :].
+ * ------------------------------------------------------------------------------------------------------- */
+int otter_qk_norm_rope_fwd(const void* qkv, const float* gamma_q, const float* beta_q, const float* gamma_k, const float* beta_k,
+                           const float* cos_t, const float* sin_t, void* q_out, void* k_out, void* v_out, float* stats, int64_t tokens,
+                           int64_t S, int64_t H, int64_t rot, float eps, void* stream);
+int64_t otter_qk_norm_rope_bwd_blocks(int64_t tokens, int64_t H);
+int otter_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv, const float* stats, const float* gamma_q,
+                           const float* gamma_k, const float* cos_t, const float* sin_t, void* dqkv, float* partial, int64_t tokens,
+                           int64_t S, int64_t H, int64_t rot, void* stream);
+int otter_sqrelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int otter_sqrelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+int otter_scatter_rows(const void* word, int word_dtype, const void* patch, int patch_dtype, const int64_t* idx, void* out, int64_t B,
+                       int64_t S, int64_t P, int64_t D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Token cross-entropy of the decoder host on bf16 logits: F.cross_entropy(logits.view(-1, V), labels) with
  * ignore_index = -100 and mean reduction     /root/reference/src/otter_ai/models/mpt/modeling_mpt.py:428-435
  * (the caller rolls the labels).  fwd: lse[r], nll[r] (0 for ignored rows) from one read of the logits; the mean

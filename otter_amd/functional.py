@@ -660,3 +660,91 @@ class PerceiverBlockFn(torch.autograd.Function):
 
         return (dx, dl.view(G, n2, D), None, None, pg(dgm, nm_w), pg(dbm, nm_w), pg(dgl, nl_w), pg(dbl, nl_w), pg(dWq, Wq),
                 pg(dWkv, Wkv), pg(dWo, Wo), pg(dgf, ff_w), pg(dbf, ff_w), pg(dW1, W1), pg(dW2, W2))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OtterHD / Fuyu path (config C5): Persimmon attention, squared ReLU, patch scatter
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class SqReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.sqrelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous() if dy.dtype == torch.bfloat16 else dy.to(torch.bfloat16).contiguous()
+        return ops.sqrelu_bwd(x, dy)
+
+
+def sqrelu(x):
+    return SqReLUFn.apply(x)
+
+
+class PersimmonAttentionFn(torch.autograd.Function):
+    """Persimmon self-attention core (fuyu/modeling_persimmon.py:262-312) on the per-head interleaved projection output
+    qkv [B,S,H*3*64] (bf16): q/k LayerNorm + partial rotary + head-dim padding in one pass (otter_qk_norm_rope_fwd), causal flash
+    attention on the padded [B,S,H,128] views (csrc/flash.hip; zero columns change neither scores nor outputs), lower 64 output
+    columns gathered into ctx [B,S,H*64].  Backward mirrors it and returns the LayerNorm parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, qkv, gq, bq, gk, bk, cos, sin, H, rot, eps, scale):
+        B, S, _ = qkv.shape
+        qkv = qkv.contiguous()
+        gqf, bqf, gkf, bkf = (t.detach().float().contiguous() for t in (gq, bq, gk, bk))
+        q, k, v, stats = ops.qk_norm_rope_fwd(qkv, gqf, bqf, gkf, bkf, cos, sin, H, rot, eps)
+        o, lse = ops.flash_attn_fwd(q, k, v, None, None, scale, True)            # [B,S,H,128]
+        ctx.save_for_backward(qkv, stats, q, k, v, o, lse, gqf, gkf, cos, sin)
+        ctx.cfg = (H, rot, scale, gq.dtype)
+        return o[..., :64].reshape(B, S, H * 64)
+
+    @staticmethod
+    def backward(ctx, dctx):
+        qkv, stats, q, k, v, o, lse, gqf, gkf, cos, sin = ctx.saved_tensors
+        H, rot, scale, pdt = ctx.cfg
+        B, S, _ = qkv.shape
+        do = torch.zeros((B, S, H, 128), dtype=torch.bfloat16, device=qkv.device)
+        do[..., :64] = dctx.reshape(B, S, H, 64)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ops.flash_attn_bwd(q, k, v, o, lse, do, dq, dk, dv, None, None, scale, True)
+        dqkv, dgq, dbq, dgk, dbk = ops.qk_norm_rope_bwd(dq, dk, dv, qkv, stats, gqf, gkf, cos, sin, H, rot)
+        return dqkv, dgq.to(pdt), dbq.to(pdt), dgk.to(pdt), dbk.to(pdt), None, None, None, None, None, None
+
+
+def persimmon_attention(qkv, q_ln, k_ln, cos, sin, n_heads, rot, scale):
+    return PersimmonAttentionFn.apply(qkv, q_ln.weight, q_ln.bias, k_ln.weight, k_ln.bias, cos.contiguous(), sin.contiguous(), n_heads, rot,
+                                      q_ln.eps, scale)
+
+
+class ScatterPatchRowsFn(torch.autograd.Function):
+    """FuyuForCausalLM.gather_continuous_embeddings (fuyu/modeling_fuyu.py:44-77) as one HIP pass; the backward routes each
+    row's gradient to the word embedding or to its patch embedding."""
+
+    @staticmethod
+    def forward(ctx, word, patch, idx):
+        idx = idx.contiguous()
+        ctx.save_for_backward(idx)
+        ctx.pshape, ctx.pdtype = patch.shape, patch.dtype
+        return ops.scatter_rows(word.contiguous(), patch.contiguous(), idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        is_patch = idx >= 0
+        dword = dy.masked_fill(is_patch[..., None], 0) if ctx.needs_input_grad[0] else None
+        dpatch = None
+        if ctx.needs_input_grad[1]:
+            B, P, D = ctx.pshape
+            dpatch = torch.zeros((B * P, D), dtype=torch.float32, device=dy.device)
+            b_ix, s_ix = torch.nonzero(is_patch, as_tuple=True)
+            dpatch.index_put_((b_ix * P + idx[b_ix, s_ix],), dy[b_ix, s_ix].float(), accumulate=True)
+            dpatch = dpatch.view(B, P, D).to(ctx.pdtype)
+        return dword, dpatch, None
+
+
+def scatter_patch_rows(word, patch, idx):
+    return ScatterPatchRowsFn.apply(word, patch, idx)

@@ -419,6 +419,75 @@ def swiglu_bwd(gu2d, dh2d):
     return dgu
 
 
+def qk_norm_rope_fwd(qkv, gq, bq, gk, bk, cos, sin, H, rot, eps):
+    """qkv [B,S,H*3*64] bf16 (per head q|k|v) -> q', k', v as [B,S,H,128] bf16 (upper 64 columns zero), stats [B*S,H,2,2]."""
+    K.require_cuda(qkv, gq, bq, gk, bk, cos, sin)
+    B, S, W = qkv.shape
+    if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or W != H * 3 * 64:
+        raise K.OtterHipError("qk_norm_rope: contiguous bf16 [B,S,H*3*64]")
+    for t in (gq, bq, gk, bk):
+        if t.dtype != torch.float32 or t.numel() != 64 or not t.is_contiguous():
+            raise K.OtterHipError("qk_norm_rope: gamma / beta must be contiguous fp32 [64]")
+    if cos.dtype != torch.float32 or not cos.is_contiguous() or tuple(cos.shape) != (S, rot) or tuple(sin.shape) != (S, rot) or not sin.is_contiguous():
+        raise K.OtterHipError("qk_norm_rope: cos / sin must be contiguous fp32 [S, rot]")
+    q = torch.empty((B, S, H, 128), dtype=torch.bfloat16, device=qkv.device)
+    k, v = torch.empty_like(q), torch.empty_like(q)
+    stats = torch.empty((B * S, H, 2, 2), dtype=torch.float32, device=qkv.device)
+    K.check(K.lib().otter_qk_norm_rope_fwd(qkv.data_ptr(), gq.data_ptr(), bq.data_ptr(), gk.data_ptr(), bk.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                           q.data_ptr(), k.data_ptr(), v.data_ptr(), stats.data_ptr(), B * S, S, H, rot, float(eps), K.stream()),
+            "qk_norm_rope_fwd")
+    return q, k, v, stats
+
+
+def qk_norm_rope_bwd(dq, dk, dv, qkv, stats, gq, gk, cos, sin, H, rot):
+    """-> (dqkv like qkv, dgamma_q, dbeta_q, dgamma_k, dbeta_k fp32 [64])."""
+    K.require_cuda(dq, dk, dv, qkv, stats)
+    B, S, _ = qkv.shape
+    for t in (dq, dk, dv):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (B, S, H, 128):
+            raise K.OtterHipError("qk_norm_rope_bwd: dq / dk / dv must be contiguous bf16 [B,S,H,128]")
+    dqkv = torch.empty_like(qkv)
+    nb = int(K.lib().otter_qk_norm_rope_bwd_blocks(B * S, H))
+    partial = torch.empty((nb, 4, 64), dtype=torch.float32, device=qkv.device)
+    K.check(K.lib().otter_qk_norm_rope_bwd(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), qkv.data_ptr(), stats.data_ptr(), gq.data_ptr(), gk.data_ptr(),
+                                           cos.data_ptr(), sin.data_ptr(), dqkv.data_ptr(), partial.data_ptr(), B * S, S, H, rot, K.stream()),
+            "qk_norm_rope_bwd")
+    p = partial.sum(0)
+    return dqkv, p[0], p[1], p[2], p[3]
+
+
+def sqrelu_fwd(x):
+    K.require_cuda(x)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.numel() % 8:
+        raise K.OtterHipError("sqrelu: contiguous bf16 tensor with numel % 8 == 0")
+    y = torch.empty_like(x)
+    K.check(K.lib().otter_sqrelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), K.stream()), "sqrelu_fwd")
+    return y
+
+
+def sqrelu_bwd(x, dy):
+    K.require_cuda(x, dy)
+    if dy.dtype != torch.bfloat16 or not dy.is_contiguous() or dy.shape != x.shape:
+        raise K.OtterHipError("sqrelu_bwd: dy must be contiguous bf16 like x")
+    dx = torch.empty_like(x)
+    K.check(K.lib().otter_sqrelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), K.stream()), "sqrelu_bwd")
+    return dx
+
+
+def scatter_rows(word, patch, idx):
+    """word [B,S,D], patch [B,P,D] (f32 or bf16 each), idx int64 [B,S] -> out like word."""
+    K.require_cuda(word, patch, idx)
+    B, S, D = word.shape
+    P = patch.shape[1]
+    if not (word.is_contiguous() and patch.is_contiguous() and idx.is_contiguous()) or idx.dtype != torch.int64 or tuple(idx.shape) != (B, S) \
+            or patch.shape[0] != B or patch.shape[2] != D:
+        raise K.OtterHipError("scatter_rows: contiguous word [B,S,D], patch [B,P,D], int64 idx [B,S]")
+    out = torch.empty_like(word)
+    K.check(K.lib().otter_scatter_rows(word.data_ptr(), K.dt(word), patch.data_ptr(), K.dt(patch), idx.data_ptr(), out.data_ptr(), B, S, P, D, K.stream()),
+            "scatter_rows")
+    return out
+
+
 def add_frame_embs_(x5, emb):
     """x5 [b,T,F,v,D] (contiguous, modified in place) += emb[:F] broadcast (modeling_otter.py:224-226)."""
     b, T, F, v, D = x5.shape

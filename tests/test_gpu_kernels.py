@@ -551,3 +551,92 @@ def test_quick_gelu_and_clip_attention_core(ops):
     p /= p.sum(-1, keepdims=True)
     ref = (p @ v).transpose(0, 2, 1, 3).reshape(N, S, D)
     assert relmax(host(o), ref) < 1e-2
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OtterHD / Fuyu kernels (config C5)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _np_layernorm(x, g, b, eps):
+    m = x.mean(-1, keepdims=True)
+    v = ((x - m) ** 2).mean(-1, keepdims=True)
+    return (x - m) / np.sqrt(v + eps) * g + b
+
+
+@pytest.mark.parametrize("rot", [32, 64, 16])
+def test_qk_norm_rope_fwd_bwd(ops, rot):
+    """q/k LayerNorm over head_dim 64 + partial rotary + padding to 128 (fuyu/modeling_persimmon.py:262-304) against fp64 numpy,
+    forward and backward (dqkv, dgamma, dbeta) -- the backward reference is a torch.autograd evaluation of the same formula."""
+    r = rng(61 + rot)
+    B, S, H, d = 2, 13, 3, 64
+    qkv = bf16_round(r.standard_normal((B, S, H, 3, d)))
+    gq, bq = (1 + 0.2 * r.standard_normal(d)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    gk, bk = (1 + 0.2 * r.standard_normal(d)).astype(np.float32), (0.1 * r.standard_normal(d)).astype(np.float32)
+    cos, sin = O.rope_tables(S, rot, base=25000.0)
+    eps = 1e-5
+    T = torch.float64
+    tq = torch.tensor(qkv, dtype=T, requires_grad=True)
+    tg = [torch.tensor(a, dtype=T, requires_grad=True) for a in (gq, bq, gk, bk)]
+
+    def ref(tq, gq_, bq_, gk_, bk_):
+        outs = []
+        for sel, (g_, b_) in enumerate(((gq_, bq_), (gk_, bk_))):
+            x = tq[..., sel, :]
+            y = torch.nn.functional.layer_norm(x, (d,), g_, b_, eps)
+            c = torch.tensor(cos, dtype=T)[None, :, None, :]
+            s_ = torch.tensor(sin, dtype=T)[None, :, None, :]
+            yr = y[..., :rot]
+            h = rot // 2
+            rh = torch.cat((-yr[..., h:], yr[..., :h]), -1)
+            outs.append(torch.cat((yr * c + rh * s_, y[..., rot:]), -1))
+        return outs[0], outs[1], tq[..., 2, :]
+
+    q_ref, k_ref, v_ref = ref(tq, *tg)
+    dev = lambda a: to_dev(a)
+    q, k, v, stats = ops.qk_norm_rope_fwd(to_dev(qkv.reshape(B, S, H * 3 * d), torch.bfloat16), dev(gq), dev(bq), dev(gk), dev(bk), dev(cos), dev(sin),
+                                          H, rot, eps)
+    assert q.shape == (B, S, H, 128)
+    for got, want in ((q, q_ref), (k, k_ref), (v, v_ref)):
+        assert relmax(host(got[..., :64]), want.detach().numpy()) < 1e-2
+        assert float(got[..., 64:].abs().max()) == 0.0
+    dq, dk, dv = (bf16_round(r.standard_normal((B, S, H, d))) for _ in range(3))
+    (q_ref * torch.tensor(dq, dtype=T)).sum().backward(retain_graph=True)
+    (k_ref * torch.tensor(dk, dtype=T)).sum().backward(retain_graph=True)
+    (v_ref * torch.tensor(dv, dtype=T)).sum().backward()
+
+    def pad(a):
+        t = torch.zeros((B, S, H, 128), dtype=torch.bfloat16, device=DEV)
+        t[..., :64] = to_dev(a, torch.bfloat16)
+        t[..., 64:] = 3.0          # the upper columns of the incoming gradients must be ignored
+        return t
+
+    dqkv, dgq, dbq, dgk, dbk = ops.qk_norm_rope_bwd(pad(dq), pad(dk), pad(dv), to_dev(qkv.reshape(B, S, H * 3 * d), torch.bfloat16), stats, dev(gq), dev(gk),
+                                                    dev(cos), dev(sin), H, rot)
+    assert relmax(host(dqkv).reshape(B, S, H, 3, d), tq.grad.numpy()) < 1.5e-2
+    for got, want in ((dgq, tg[0]), (dbq, tg[1]), (dgk, tg[2]), (dbk, tg[3])):
+        assert relmax(host(got), want.grad.numpy()) < 1e-3
+
+
+def test_sqrelu_and_scatter_rows(ops):
+    r = rng(67)
+    x = bf16_round(r.standard_normal((19, 256)) * 2)
+    dy = bf16_round(r.standard_normal((19, 256)))
+    y = ops.sqrelu_fwd(to_dev(x, torch.bfloat16))
+    assert relmax(host(y), np.maximum(x, 0) ** 2) < 8e-3
+    dx = ops.sqrelu_bwd(to_dev(x, torch.bfloat16), to_dev(dy, torch.bfloat16))
+    assert relmax(host(dx), 2 * np.maximum(x, 0) * dy) < 8e-3
+    B, S, P, D = 2, 11, 5, 64
+    word = r.standard_normal((B, S, D)).astype(np.float32)
+    patch = bf16_round(r.standard_normal((B, P, D)))
+    idx = np.full((B, S), -1, np.int64)
+    idx[0, 2:7] = [0, 1, 2, 3, 4]
+    idx[1, 0:3] = [4, 0, 2]
+    ref = word.copy()
+    for b in range(B):
+        for s in range(S):
+            if idx[b, s] >= 0:
+                ref[b, s] = patch[b, idx[b, s]]
+    for wdt, pdt in ((torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)):
+        out = ops.scatter_rows(to_dev(word, wdt), to_dev(patch, pdt), torch.from_numpy(idx).to(DEV))
+        assert relmax(host(out), ref) < (1e-6 if wdt == torch.float32 else 8e-3)
