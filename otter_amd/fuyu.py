@@ -60,12 +60,12 @@ class PersimmonMLP(nn.Module):
         self.dense_4h_to_h = nn.Linear(config.intermediate_size, config.hidden_size)
 
     def forward(self, x):
-        h = self.dense_h_to_4h(x)
+        h = OF.trainable_linear(self.dense_h_to_4h, x)
         if h.is_cuda and h.dtype == torch.bfloat16 and h.shape[-1] % 8 == 0:
             h = OF.sqrelu(h)
         else:
             h = torch.square(F.relu(h))
-        return self.dense_4h_to_h(h)
+        return OF.trainable_linear(self.dense_4h_to_h, h)
 
 
 class PersimmonAttention(nn.Module):
@@ -98,10 +98,10 @@ class PersimmonAttention(nn.Module):
     def forward(self, x, cos, sin, attn_mask=None, past_key_value=None, use_cache=False, hip=False):
         B, S, _ = x.shape
         H, d = self.n_heads, self.head_dim
-        qkv = self.query_key_value(x)                                           # [B,S,H*3*d], per head (q | k | v)
+        qkv = OF.trainable_linear(self.query_key_value, x)                      # [B,S,H*3*d], per head (q | k | v)
         if hip:
             ctx = OF.persimmon_attention(qkv, self.q_layernorm, self.k_layernorm, cos, sin, H, self.rot, self.scale)
-            return self.dense(ctx), None
+            return OF.trainable_linear(self.dense, ctx), None
         q5 = qkv.view(B, S, H, 3, d)
         q, k, v = q5[..., 0, :], q5[..., 1, :], q5[..., 2, :]
         if self.qk_layernorm:
@@ -263,7 +263,7 @@ class PersimmonForCausalLM(PersimmonPreTrainedModel):
                 use_cache=None, return_dict=True, **unused):
         out = self.model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids, past_key_values=past_key_values,
                          inputs_embeds=inputs_embeds, use_cache=use_cache)
-        logits = self.lm_head(out.last_hidden_state)
+        logits = OF.trainable_linear(self.lm_head, out.last_hidden_state)
         loss = None
         if labels is not None:
             lab = torch.full_like(labels, -100)
