@@ -81,6 +81,11 @@ class SharedEmbedding(nn.Embedding):
 
     def forward(self, input: torch.Tensor, unembed: bool = False) -> torch.Tensor:
         if unembed:
+            if self.weight.requires_grad and self.weight.dtype == torch.float32 and input.is_cuda and input.dtype == torch.bfloat16:
+                # trainable fp32 master (the reference unfreezes the input embeddings, modeling_otter.py:905): bf16 operand copy
+                # from the shadow cache the AdamW kernel refreshes, fp32 weight gradient straight out of the GEMM -- instead of
+                # a 413 MB cast of the table every forward and a 826 MB cast of its gradient every backward (0.8 ms per step)
+                return OF.TrainableLinearFn.apply(input, self.weight, None)
             return F.linear(input, self.weight.to(input.dtype))
         return super().forward(input)
 
