@@ -103,11 +103,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // Phi(u) = 0.5 (1 + erf(u / sqrt 2)) and phi(u) = exp(-u^2/2) / sqrt(2 pi) from ONE exponential:
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class), 1 rcp + 5 fma + 1 v_exp_f32 instead of
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class), 1 v_rcp_f32 + 5 fma + 1 v_exp_f32 instead of
 // libm's branchy erff (~40 VALU) plus a separate expf.  Used by the GEMM epilogues (GELU forward, gate/GELU backward).
 __device__ __forceinline__ void gelu_cdf_pdf(float u, float& cdf, float& pdf) {
     const float x = fabsf(u) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));  // v_rcp_f32 (1 ulp); __frcp_rn expands to the 11-instruction IEEE division
     const float e = __expf(-x * x);  // = exp(-u^2 / 2)
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);

@@ -178,7 +178,7 @@ __global__ void quick_gelu_kernel(const T* __restrict__ x, T* __restrict__ y, in
     float v[8];
     Vec8<T>::load(x + 8 * t, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.0f + __expf(-1.702f * v[i]));
+    for (int i = 0; i < 8; ++i) v[i] = v[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[i]));
     Vec8<T>::store(y + 8 * t, v);
 }
 
@@ -193,7 +193,7 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restr
     Vec8<bf16_t>::load(gu + row * 2 * I + 8 * c, g);
     Vec8<bf16_t>::load(gu + row * 2 * I + I + 8 * c, u);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = g[i] / (1.0f + __expf(-g[i])) * u[i];
+    for (int i = 0; i < 8; ++i) o[i] = g[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-g[i])) * u[i];
     Vec8<bf16_t>::store(h + row * I + 8 * c, o);
 }
 __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dh, bf16_t* __restrict__ dgu, int64_t I,
@@ -207,7 +207,7 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* _
     Vec8<bf16_t>::load(dh + row * I + 8 * c, d);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float sg = 1.0f / (1.0f + __expf(-g[i]));
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-g[i]));
         const float silu = g[i] * sg;
         du[i] = d[i] * silu;
         dg[i] = d[i] * u[i] * (sg + silu * (1.0f - sg));   // silu'(g) = sg * (1 + g * (1 - sg))

@@ -121,15 +121,18 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
         default: {  // OTTER_EPI_GATE_BWD
             float a[4];
             load4(g.aux, m * g.ldaux + n, g.auxdt, a);
+            if (g.aux_gelu) {   // tested outside the element loop (a per-element scalar branch serialises the chains)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (g.aux_gelu) {
+                for (int i = 0; i < 4; ++i) {
                     // gelu and gelu' share the erf: one transcendental chain instead of two
                     float cdf, pdf;
                     gelu_cdf_pdf(a[i], cdf, pdf);
                     part += v[i] * (a[i] * cdf);
                     o[i] = s * v[i] * (cdf + a[i] * pdf);
-                } else {
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
                     part += v[i] * a[i];
                     o[i] = s * v[i];
                 }
@@ -202,14 +205,17 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m
         default: {  // OTTER_EPI_GATE_BWD
             float a[8];
             load8w(g.aux, m * g.ldaux + n, g.auxdt, a);
+            if (g.aux_gelu) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (g.aux_gelu) {
+                for (int i = 0; i < 8; ++i) {
                     float cdf, pdf;
                     gelu_cdf_pdf(a[i], cdf, pdf);
                     part += v[i] * (a[i] * cdf);
                     o[i] = s * v[i] * (cdf + a[i] * pdf);
-                } else {
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
                     part += v[i] * a[i];
                     o[i] = s * v[i];
                 }
@@ -324,9 +330,11 @@ __device__ __forceinline__ bool tail_input(const GemmArgs& g, const void*& p, in
     else { p = nullptr; ld = 0; dt = OTTER_F32; return false; }
 }
 // raw (unconverted) input of NE elements: the conversion to f32 stays with the consumer so that no use sits next to the load
-template <int NE>
-__device__ __forceinline__ void load_raw(const void* p, int64_t idx, int dt, uint4 (&raw)[2]) {
-    if (dt == OTTER_BF16) {
+// INBF16: the input dtype as a TEMPLATE parameter -- as a run-time test inside each load it made the compiler emit a branch and
+// an `s_waitcnt vmcnt(0)` between consecutive loads (the "prefetch" ran one memory latency per access)
+template <int NE, bool INBF16>
+__device__ __forceinline__ void load_raw(const void* p, int64_t idx, uint4 (&raw)[2]) {
+    if constexpr (INBF16) {
         if constexpr (NE == 8) raw[0] = *reinterpret_cast<const uint4*>((const bf16_t*)p + idx);
         else { const uint2 t = *reinterpret_cast<const uint2*>((const bf16_t*)p + idx); raw[0].x = t.x; raw[0].y = t.y; }
     } else {
@@ -334,9 +342,9 @@ __device__ __forceinline__ void load_raw(const void* p, int64_t idx, int dt, uin
         if constexpr (NE == 8) raw[1] = *reinterpret_cast<const uint4*>((const float*)p + idx + 4);
     }
 }
-template <int NE>
-__device__ __forceinline__ void cvt_raw(const uint4 (&raw)[2], int dt, float (&a)[NE]) {
-    if (dt == OTTER_BF16) {
+template <int NE, bool INBF16>
+__device__ __forceinline__ void cvt_raw(const uint4 (&raw)[2], float (&a)[NE]) {
+    if constexpr (INBF16) {
         const uint32_t w[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w};
 #pragma unroll
         for (int i = 0; i < NE / 2; ++i) { a[2 * i] = __uint_as_float(w[i] << 16); a[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
@@ -354,8 +362,13 @@ __device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t 
     float part = 0.f;
     float o[NE];
     if constexpr (EPI == OTTER_EPI_STORE) {
+        if (has_in) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) o[i] = has_in ? a[i] + s * v[i] : s * v[i];
+            for (int i = 0; i < NE; ++i) o[i] = a[i] + s * v[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) o[i] = s * v[i];
+        }
     } else if constexpr (EPI == OTTER_EPI_GELU) {
         if (g.C2) {
             if constexpr (NE == 8) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
@@ -371,14 +384,19 @@ __device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t 
 #pragma unroll
         for (int i = 0; i < NE; ++i) o[i] = v[i] * s + a[i];
     } else {
+        // the aux kind is tested ONCE, outside the element loop: inside it the compiler kept a scalar branch between
+        // elements, which serialised eight independent rcp / exp / fma chains (gate-backward tail: 88 k cycles per tile)
+        if (g.aux_gelu) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            if (g.aux_gelu) {
+            for (int i = 0; i < NE; ++i) {
                 float cdf, pdf;
                 gelu_cdf_pdf(a[i], cdf, pdf);
                 part += v[i] * (a[i] * cdf);
                 o[i] = s * v[i] * (cdf + a[i] * pdf);
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
                 part += v[i] * a[i];
                 o[i] = s * v[i];
             }
@@ -396,17 +414,17 @@ struct TailShape {  // bf16 output: 4 accesses of 8 columns per lane and stripe;
     static __device__ __forceinline__ int col(int lane) { return CBF16 ? (lane & 7) * 8 : (lane & 15) * 4; }
 };
 
-template <int EPI, bool CBF16>
-__device__ __forceinline__ void tail_stripe_load(const void* p, int64_t ld, int dt, int64_t m_base, int64_t n_base, int lane,
+template <int EPI, bool CBF16, bool INBF16>
+__device__ __forceinline__ void tail_stripe_load(const void* p, int64_t ld, int64_t m_base, int64_t n_base, int lane,
                                                  uint4 (&raw)[TailShape<CBF16>::NIT][2]) {
     using T = TailShape<CBF16>;
 #pragma unroll
-    for (int it = 0; it < T::NIT; ++it) load_raw<T::NE>(p, (m_base + T::row(lane, it)) * ld + n_base + T::col(lane), dt, raw[it]);
+    for (int it = 0; it < T::NIT; ++it) load_raw<T::NE, INBF16>(p, (m_base + T::row(lane, it)) * ld + n_base + T::col(lane), raw[it]);
 }
 
-template <int EPI, bool CBF16>
+template <int EPI, bool CBF16, bool INBF16>
 __device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const float* __restrict__ blk, int64_t m_base, int64_t n_base, int lane,
-                                                  const uint4 (&raw)[TailShape<CBF16>::NIT][2], int in_dt, bool has_in) {
+                                                  const uint4 (&raw)[TailShape<CBF16>::NIT][2], bool has_in) {
     using T = TailShape<CBF16>;
     float part = 0.f;
     g.cdt = CBF16 ? OTTER_BF16 : OTTER_F32;  // compile-time constant from here on: the dtype switches of the stores fold away
@@ -424,7 +442,7 @@ __device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const flo
 #pragma unroll
     for (int it = 0; it < T::NIT; ++it) {
         float a[T::NE];
-        if (has_in) cvt_raw<T::NE>(raw[it], in_dt, a);
+        if (has_in) cvt_raw<T::NE, INBF16>(raw[it], a);
         else {
 #pragma unroll
             for (int i = 0; i < T::NE; ++i) a[i] = 0.f;
@@ -443,15 +461,13 @@ __device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const flo
 constexpr int TAIL_STRIPES = 4;
 constexpr int TAIL_LDS_BYTES = 4 * TAIL_STRIPES * 32 * EPI_LD * 4;  // 4 waves: 139264 B
 
-template <int EPI, bool CBF16>
-__device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4 /* 4 stripes */,
-                                                int64_t m_wave, int64_t n_wave, int lane) {
+template <int EPI, bool CBF16, bool INBF16>
+__device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4 /* 4 stripes */,
+                                                  int64_t m_wave, int64_t n_wave, int lane, const void* ip, int64_t ild, bool has_in) {
     using T = TailShape<CBF16>;
     float part = 0.f;
-    const void* ip; int64_t ild; int idt;
-    const bool has_in = tail_input<EPI>(g, ip, ild, idt);
     uint4 cur[T::NIT][2], nxt[T::NIT][2];
-    if (has_in) tail_stripe_load<EPI, CBF16>(ip, ild, idt, m_wave, n_wave, lane, cur);   // stripe 0
+    if (has_in) tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave, lane, cur);   // stripe 0
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -465,15 +481,28 @@ __device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, cons
         for (int q = 0; q < TAIL_STRIPES; ++q) {
             const int st = half * TAIL_STRIPES + q;
             if (has_in && st + 1 < 8)   // request the next stripe's input before this stripe's arithmetic
-                tail_stripe_load<EPI, CBF16>(ip, ild, idt, m_wave + ((st + 1) >> 1) * 32, n_wave + ((st + 1) & 1) * 64, lane, nxt);
-            part += tail_stripe_full<EPI, CBF16>(g, s, blk4 + q * (32 * EPI_LD), m_wave + (st >> 1) * 32, n_wave + (st & 1) * 64, lane, cur, idt,
-                                                 has_in);
+                tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + ((st + 1) >> 1) * 32, n_wave + ((st + 1) & 1) * 64, lane, nxt);
+            part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk4 + q * (32 * EPI_LD), m_wave + (st >> 1) * 32, n_wave + (st & 1) * 64, lane, cur,
+                                                         has_in);
 #pragma unroll
             for (int it = 0; it < T::NIT; ++it) { cur[it][0] = nxt[it][0]; cur[it][1] = nxt[it][1]; }
         }
         __builtin_amdgcn_wave_barrier();
     }
     return part;
+}
+
+template <int EPI, bool CBF16>
+__device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4, int64_t m_wave,
+                                                int64_t n_wave, int lane) {
+    const void* ip; int64_t ild; int idt;
+    const bool has_in = tail_input<EPI>(g, ip, ild, idt);
+    if constexpr (EPI == OTTER_EPI_GELU) {       // no global input at all: one instantiation
+        return tail_wave_full_t<EPI, CBF16, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, false);
+    } else {
+        if (idt == OTTER_BF16) return tail_wave_full_t<EPI, CBF16, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
+        return tail_wave_full_t<EPI, CBF16, false>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
+    }
 }
 
 __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int bid, int& tile_m, int& tile_n) {
