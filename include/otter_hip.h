@@ -262,6 +262,19 @@ int otter_add_frame_embs(void* x, int x_dtype, const float* emb, int64_t outer, 
 int otter_add_rows(void* dst, const void* src, otter_rowmap src_map, int64_t rows, int64_t D, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Single-query attention over a KV cache: the cached decode step of generate() (/root/reference/src/otter_ai/models/otter/
+ * modeling_otter.py:999-1042 -> mpt/attention.py:22-84 with past_key_value + ALiBi :447-464; LLaMA llama.py:169-213).
+ * q, o [B, H, 128] (bf16); K and V are addressed by explicit batch / head / key / dim strides (elements), so the reference's
+ * MPT cache layout k [B,H,d,S], v [B,H,S,d] and the [B,H,S,d] layout of the LLaMA host are both read in place.
+ * alibi_slopes [H] fp32 or NULL (bias slope * (j - (Sk-1))); key_valid [B, Sk] (0 = padded key) or NULL.  Sk <= 16384.
+ * ------------------------------------------------------------------------------------------------------- */
+int otter_decode_attn(const void* q, int64_t q_batch_stride, int64_t q_head_stride, const void* k, int64_t k_batch_stride,
+                      int64_t k_head_stride, int64_t k_key_stride, int64_t k_dim_stride, const void* v, int64_t v_batch_stride,
+                      int64_t v_head_stride, int64_t v_key_stride, int64_t v_dim_stride, void* o, int64_t o_batch_stride,
+                      int64_t o_head_stride, const float* alibi_slopes, const uint8_t* key_valid, int64_t B, int64_t H, int64_t Sk,
+                      int64_t head_dim, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * OtterHD / Fuyu-8B path (config C5): row-wise kernels of the Persimmon decoder and the patch scatter.
  *   otter_qk_norm_rope_fwd  /root/reference/src/otter_ai/models/fuyu/modeling_persimmon.py:262-304: the per-head interleaved
  *       projection output qkv [tokens, H, 3, 64] (bf16) is read in place; q and k get LayerNorm over the 64-wide head

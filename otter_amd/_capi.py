@@ -98,6 +98,8 @@ SIGNATURES = {
     "otter_flash_attn_fwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_flash_attn_bwd": (_int, [C.POINTER(FlashDesc), _vp]),
     "otter_flash_set_variant": (_int, [_int]),
+    "otter_decode_attn": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
+                                 _i64, _f32, _vp]),
     "otter_qk_norm_rope_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "otter_qk_norm_rope_bwd_blocks": (_i64, [_i64, _i64]),
     "otter_qk_norm_rope_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libotter_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "flash.hip", "optim.hip", "attn_mfma.hip", "loss.hip", "fuyu.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "flash.hip", "optim.hip", "attn_mfma.hip", "loss.hip", "fuyu.hip", "decode.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-unused-value"]
 
 

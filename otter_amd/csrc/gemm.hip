@@ -1805,6 +1805,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 7],
                                                          kt * 128, 0, 0);
         };
+        // ---- prologue: K-tiles 0 and 1 in flight, 0 readable; the 256 accumulator registers are zeroed while they land ----
+#pragma unroll
+        for (int p = 0; p < 16; ++p) dma(0, 0, p);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) dma(1, 1, p);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16_t acc[4][4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
@@ -1812,12 +1818,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-        // ---- prologue: K-tiles 0 and 1 in flight, 0 readable ----
-#pragma unroll
-        for (int p = 0; p < 16; ++p) dma(0, 0, p);
-#pragma unroll
-        for (int p = 0; p < 16; ++p) dma(1, 1, p);
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

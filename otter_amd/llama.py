@@ -168,6 +168,11 @@ class LlamaAttention(nn.Module):
             k = torch.cat([past_key_value[0], k], dim=2)
             v = torch.cat([past_key_value[1], v], dim=2)
         new_past = (k, v) if use_cache else None
+        if (S == 1 and k.shape[2] > 1 and x.is_cuda and q.dtype == torch.bfloat16 and d == 128 and Hk == H
+                and os.environ.get("OTTER_NO_FLASH") != "1"):
+            # cached decode step on HIP (csrc/decode.hip): one query over the [B,H,S,d] cache, read in place
+            o = ops.decode_attn(q[:, :, 0], k, v, None, key_valid, self.scale)
+            return self.o_proj(o.reshape(B, 1, H * d)), new_past
         if Hk != H:
             k = k.repeat_interleave(H // Hk, dim=1)
             v = v.repeat_interleave(H // Hk, dim=1)
@@ -274,6 +279,8 @@ class LlamaModel(LlamaPreTrainedModel):
         if flash:
             key_valid = am.to(torch.uint8).contiguous() if am is not None else None
         else:
+            if S == 1 and s_past > 0 and am is not None:
+                key_valid = am[:, -s_k:].to(torch.uint8).contiguous()      # for the HIP decode step (padded keys masked)
             cd = OF.compute_dtype_for(x)
             neg = torch.finfo(torch.float32).min
             mask = torch.zeros(1, 1, S, s_k, dtype=torch.float32, device=x.device)

@@ -151,6 +151,12 @@ class MPTMLP(nn.Module):
         return self.down_proj(self.act(self.up_proj(x)))
 
 
+def ops_decode_attn(q, k, v, slopes, key_valid, scale):
+    from . import ops
+
+    return ops.decode_attn(q, k, v, slopes, key_valid, scale)
+
+
 class MultiheadAttention(nn.Module):
     def __init__(self, d_model, n_heads, bias):
         super().__init__()
@@ -159,10 +165,19 @@ class MultiheadAttention(nn.Module):
         self.Wqkv = FrozenAwareLinear(d_model, 3 * d_model, bias=bias)
         self.out_proj = FrozenAwareLinear(d_model, d_model, bias=bias)
 
-    def forward(self, x, past_key_value=None, attn_bias=None, is_causal=True, flash=None):
+    def forward(self, x, past_key_value=None, attn_bias=None, is_causal=True, flash=None, decode=None):
         B, S, D = x.shape
         H, d = self.n_heads, D // self.n_heads
         qkv = self.Wqkv(x)
+        if decode is not None and past_key_value is not None and len(past_key_value) != 0 and S == 1:
+            # cached decode step on HIP (csrc/decode.hip): the new key / value are appended to the cache in the reference's
+            # layout (k [B,H,d,S], v [B,H,S,d]) and the single query attends over it in place -- no SDPA, no [B,H,1,S] bias tensor
+            slopes, key_valid = decode
+            q5 = qkv.view(B, 1, 3, H, d)
+            k = torch.cat([past_key_value[0], q5[:, 0, 1].unsqueeze(-1)], dim=3)            # [B,H,d,S+1]
+            v = torch.cat([past_key_value[1], q5[:, 0, 2].unsqueeze(2)], dim=2)             # [B,H,S+1,d]
+            o = ops_decode_attn(q5[:, 0, 0], k.transpose(2, 3), v, slopes, key_valid, self.softmax_scale)
+            return self.out_proj(o.reshape(B, 1, D)), (k, v)
         if flash is not None:
             # HIP flash attention on the fused projection output (otter_amd/csrc/flash.hip): ALiBi, causal and key-padding
             # masks are evaluated inside the kernel, q/k/v and their gradients are slices of one buffer
@@ -200,7 +215,7 @@ class MPTBlock(nn.Module):
         self.ffn = MPTMLP(config.d_model, config.expansion_ratio, bias)
 
     def forward(self, x, past_key_value=None, attn_bias=None, attention_mask=None, is_causal=True, deferred=None,
-                defer_out=False, flash=None):
+                defer_out=False, flash=None, decode=None):
         """`deferred` / `defer_out` (otter_amd extension, used by MPTModel.forward): the FFN output of a block is handed to
         the NEXT block un-added, where the residual add is fused into that block's norm_1 pass (one trip over the fp32
         residual stream instead of two).  With the defaults this is exactly mpt/blocks.py:68-88."""
@@ -208,7 +223,7 @@ class MPTBlock(nn.Module):
             x, a = self.norm_1.add_forward(x, deferred)   # x = x + ffn_out(prev) ; a = norm_1(x)
         else:
             a = self.norm_1(x)
-        b, past_key_value = self.attn(a, past_key_value=past_key_value, attn_bias=attn_bias, is_causal=is_causal, flash=flash)
+        b, past_key_value = self.attn(a, past_key_value=past_key_value, attn_bias=attn_bias, is_causal=is_causal, flash=flash, decode=decode)
         x, m = self.norm_2.add_forward(x, b)              # x = x + b ; m = norm_2(x)
         n = self.ffn(m)
         if defer_out:
@@ -282,6 +297,23 @@ class MPTModel(MPTPreTrainedModel):
             self._slopes = alibi_slopes(self.config.n_heads, self.alibi_bias_max).to(x.device)
         return self._slopes.float().contiguous(), key_valid
 
+    def _decode_spec(self, x, S, s_past, attention_mask):
+        """(alibi slopes, key_valid or None) when the HIP decode kernel covers this call: one new token over a non-empty cache,
+        bf16 compute on the GPU, head_dim 128.  Left-padded prompts are fine here (padded keys are masked, the current token is
+        always valid)."""
+        if not x.is_cuda or S != 1 or s_past == 0 or OF.compute_dtype_for(x) != torch.bfloat16 or os.environ.get("OTTER_NO_FLASH") == "1":
+            return None
+        if self.config.d_model // self.config.n_heads != 128:
+            return None
+        key_valid = None
+        if attention_mask is not None:
+            am = attention_mask.bool()[:, -(s_past + 1):]
+            if not bool(am.all()):
+                key_valid = am.to(torch.uint8).contiguous()
+        if self._slopes is None or self._slopes.device != x.device:
+            self._slopes = alibi_slopes(self.config.n_heads, self.alibi_bias_max).to(x.device)
+        return self._slopes.float().contiguous(), key_valid
+
     def forward(self, input_ids, past_key_values=None, attention_mask=None, use_cache=None, return_dict=True, **unused):
         use_cache = use_cache if use_cache is not None else self.config.use_cache
         if attention_mask is not None and self.training and int(attention_mask[:, 0].sum()) != attention_mask.shape[0]:
@@ -295,7 +327,8 @@ class MPTModel(MPTPreTrainedModel):
             s_past = past_key_values[0][0].size(3)
         s_k = S + s_past
         flash, attn_bias = self._flash_spec(x, s_past, attention_mask), None
-        if flash is None:
+        decode = self._decode_spec(x, S, s_past, attention_mask) if flash is None else None
+        if flash is None and decode is None:
             # one additive mask per forward, shared by every block: ALiBi (+ padding) and, for S > 1, the causal triangle
             attn_bias = self._attn_bias(s_k, x.device, attention_mask)
             if self.is_causal and S != 1:
@@ -316,7 +349,7 @@ class MPTModel(MPTPreTrainedModel):
                 x = x + delta
                 delta = None
             out = block(x, past_key_value=pkv, attn_bias=attn_bias, attention_mask=None, is_causal=self.is_causal,
-                        deferred=delta, defer_out=True, flash=flash)
+                        deferred=delta, defer_out=True, flash=flash, decode=decode)
             x, pkv = out[0], out[2]
             delta = out[3] if len(out) > 3 else None
             if past_key_values is not None:

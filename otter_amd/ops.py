@@ -419,6 +419,26 @@ def swiglu_bwd(gu2d, dh2d):
     return dgu
 
 
+def decode_attn(q, k, v, slopes, key_valid, scale):
+    """Single-query attention over a KV cache.  q [B,H,128] bf16; k, v: 4-d bf16 tensors indexed [b, h, key, dim] through their own
+    strides (pass `k_cache.transpose(2, 3)` for the MPT layout [B,H,d,S]); slopes fp32 [H] or None; key_valid uint8 [B,Sk] or None.
+    Returns o [B,H,128]."""
+    K.require_cuda(q, k, v, slopes, key_valid)
+    B, H, d = q.shape
+    Sk = k.shape[2]
+    if q.dtype != torch.bfloat16 or k.dtype != torch.bfloat16 or v.dtype != torch.bfloat16 or d != 128 or q.stride(2) != 1:
+        raise K.OtterHipError("decode_attn: bf16, head_dim 128, unit-stride q")
+    if tuple(k.shape) != (B, H, Sk, d) or tuple(v.shape) != (B, H, Sk, d):
+        raise K.OtterHipError("decode_attn: k, v must be indexable as [B,H,Sk,128]")
+    if key_valid is not None and (key_valid.dtype != torch.uint8 or not key_valid.is_contiguous() or tuple(key_valid.shape) != (B, Sk)):
+        raise K.OtterHipError("decode_attn: key_valid must be contiguous uint8 [B,Sk]")
+    o = torch.empty((B, H, d), dtype=torch.bfloat16, device=q.device)
+    K.check(K.lib().otter_decode_attn(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1), k.stride(2), k.stride(3),
+                                      v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), v.stride(3), o.data_ptr(), o.stride(0), o.stride(1),
+                                      K.ptr(slopes), K.ptr(key_valid), B, H, Sk, d, float(scale), K.stream()), "decode_attn")
+    return o
+
+
 def qk_norm_rope_fwd(qkv, gq, bq, gk, bk, cos, sin, H, rot, eps):
     """qkv [B,S,H*3*64] bf16 (per head q|k|v) -> q', k', v as [B,S,H,128] bf16 (upper 64 columns zero), stats [B*S,H,2,2]."""
     K.require_cuda(qkv, gq, bq, gk, bk, cos, sin)

@@ -640,3 +640,40 @@ def test_sqrelu_and_scatter_rows(ops):
     for wdt, pdt in ((torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)):
         out = ops.scatter_rows(to_dev(word, wdt), to_dev(patch, pdt), torch.from_numpy(idx).to(DEV))
         assert relmax(host(out), ref) < (1e-6 if wdt == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("layout", ["mpt", "llama"])
+def test_decode_attention_over_kv_cache(ops, layout):
+    """csrc/decode.hip: one query over a KV cache in the reference's MPT layout (k [B,H,d,S], v [B,H,S,d]) and in the LLaMA host's
+    [B,H,S,d] layout, with ALiBi, a padding mask and a ragged Sk, against an fp64 softmax attention."""
+    r = rng(71)
+    B, H, Sk, d = 3, 5, 77, 128
+    q = bf16_round(r.standard_normal((B, H, d)))
+    k = bf16_round(r.standard_normal((B, H, Sk, d)))
+    v = bf16_round(r.standard_normal((B, H, Sk, d)))
+    slopes = (2.0 ** -np.arange(1, H + 1)).astype(np.float32) if layout == "mpt" else None
+    valid = np.ones((B, Sk), np.uint8)
+    valid[1, :9] = 0
+    scale = d ** -0.5
+    s = np.einsum("bhd,bhsd->bhs", q.astype(np.float64), k.astype(np.float64)) * scale
+    if slopes is not None:
+        s = s + slopes[None, :, None] * (np.arange(Sk) - (Sk - 1))[None, None, :]
+    s = np.where(valid[:, None, :] != 0, s, -np.inf)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bhs,bhsd->bhd", p, v.astype(np.float64))
+    tq, tv = to_dev(q, torch.bfloat16), to_dev(v, torch.bfloat16)
+    if layout == "mpt":
+        tk = to_dev(k.transpose(0, 1, 3, 2).copy(), torch.bfloat16).transpose(2, 3)      # storage [B,H,d,S], indexed [b,h,s,d]
+        assert tk.stride(2) == 1
+    else:
+        tk = to_dev(k, torch.bfloat16)
+    o = ops.decode_attn(tq, tk, tv, to_dev(slopes) if slopes is not None else None, torch.from_numpy(valid).to(DEV), scale)
+    assert relmax(host(o), ref) < 1e-2
+    o2 = ops.decode_attn(tq, tk, tv, to_dev(slopes) if slopes is not None else None, None, scale)     # no mask
+    s2 = np.einsum("bhd,bhsd->bhs", q.astype(np.float64), k.astype(np.float64)) * scale
+    if slopes is not None:
+        s2 = s2 + slopes[None, :, None] * (np.arange(Sk) - (Sk - 1))[None, None, :]
+    p2 = np.exp(s2 - s2.max(-1, keepdims=True))
+    p2 /= p2.sum(-1, keepdims=True)
+    assert relmax(host(o2), np.einsum("bhs,bhsd->bhd", p2, v.astype(np.float64))) < 1e-2
