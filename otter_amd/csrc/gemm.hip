@@ -461,25 +461,25 @@ __device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const flo
 constexpr int TAIL_STRIPES = 4;
 constexpr int TAIL_LDS_BYTES = 4 * TAIL_STRIPES * 32 * EPI_LD * 4;  // 4 waves: 139264 B
 
-template <int EPI, bool CBF16, bool INBF16>
-__device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4 /* 4 stripes */,
+template <int EPI, bool CBF16, bool INBF16, int NS>
+__device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4 /* NS stripes */,
                                                   int64_t m_wave, int64_t n_wave, int lane, const void* ip, int64_t ild, bool has_in) {
     using T = TailShape<CBF16>;
     float part = 0.f;
     uint4 cur[T::NIT][2], nxt[T::NIT][2];
     if (has_in) tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave, lane, cur);   // stripe 0
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < 8 / NS; ++half) {
 #pragma unroll
-        for (int q = 0; q < TAIL_STRIPES; ++q) {
-            const int st = half * TAIL_STRIPES + q;
+        for (int q = 0; q < NS; ++q) {
+            const int st = half * NS + q;
             park_block(blk4 + q * (32 * EPI_LD), acc[st >> 1][2 * (st & 1)], lane, 0);
             park_block(blk4 + q * (32 * EPI_LD), acc[st >> 1][2 * (st & 1) + 1], lane, 32);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-        for (int q = 0; q < TAIL_STRIPES; ++q) {
-            const int st = half * TAIL_STRIPES + q;
+        for (int q = 0; q < NS; ++q) {
+            const int st = half * NS + q;
             if (has_in && st + 1 < 8)   // request the next stripe's input before this stripe's arithmetic
                 tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + ((st + 1) >> 1) * 32, n_wave + ((st + 1) & 1) * 64, lane, nxt);
             part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk4 + q * (32 * EPI_LD), m_wave + (st >> 1) * 32, n_wave + (st & 1) * 64, lane, cur,
@@ -492,16 +492,16 @@ __device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, co
     return part;
 }
 
-template <int EPI, bool CBF16>
+template <int EPI, bool CBF16, int NS = TAIL_STRIPES>
 __device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4, int64_t m_wave,
                                                 int64_t n_wave, int lane) {
     const void* ip; int64_t ild; int idt;
     const bool has_in = tail_input<EPI>(g, ip, ild, idt);
     if constexpr (EPI == OTTER_EPI_GELU) {       // no global input at all: one instantiation
-        return tail_wave_full_t<EPI, CBF16, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, false);
+        return tail_wave_full_t<EPI, CBF16, true, NS>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, false);
     } else {
-        if (idt == OTTER_BF16) return tail_wave_full_t<EPI, CBF16, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
-        return tail_wave_full_t<EPI, CBF16, false>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
+        if (idt == OTTER_BF16) return tail_wave_full_t<EPI, CBF16, true, NS>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
+        return tail_wave_full_t<EPI, CBF16, false, NS>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
     }
 }
 
@@ -1736,7 +1736,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
 // slots, at most one filler each) -- generated by tools/gen/gemm_r4_schedule.py, see its header.
 // Requires K % 128 == 0 and operands spanning < 4 GB.
 // ------------------------------------------------------------------------------------------------------------
-template <int EPI, int SCH>
+template <int EPI, int SCH, bool PF>
 __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, NT = 256;
     constexpr int TILE = (BM + BN) * 128;  // 64 KB: [256 A rows ; 256 B rows] x 128 B
@@ -1779,35 +1779,51 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
     } while (0)
 
     const int ntiles = g.gm * g.gn;
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-        int tile_m, tile_n;
-        tile_of_block(g, vb, tile_m, tile_n);
-        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-        TMARK(0);
-        uint32_t oa[8], ob[8];
+    // PF (variant 21): the DMA of the NEXT tile's first K-tile is issued before the current tile's tail (both buffers are dead once
+    // a wave leaves the K loop: every wave has passed barrier #1 of the last K-tile); the tail then parks in the second buffer
+    // (two stripes per phase) and the first buffer fills under it.  Counted vmcnt stays valid with the tail's stores in flight:
+    // loads retire in order among themselves, `vmcnt(16)` after the 16 pieces of K-tile 1 covers everything older.
+    uint32_t oa[8], ob[8];
+    auto set_offsets = [&](int64_t m0_, int64_t n0_) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int c = i * NT + tid, row = c >> 3, phys = c & 7;
             const int slot = phys ^ ((row >> 1) & 7);
-            int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
-            int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
+            int64_t ga = m0_ + row; if (ga > g.M - 1) ga = g.M - 1;
+            int64_t gb = n0_ + row; if (gb > g.N - 1) gb = g.N - 1;
             oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
             ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
         }
-        // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
-        auto dma = [&](int bufv, int kt, int p) {
-            if constexpr ((OTTER_DIAG & 1) != 0) return;
-            const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
-            if (p < 8)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p & 7],
-                                                         kt * 128, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 7],
-                                                         kt * 128, 0, 0);
-        };
+    };
+    // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
+    auto dma = [&](int bufv, int kt, int p) {
+        if constexpr ((OTTER_DIAG & 1) != 0) return;
+        const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
+        if (p < 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p & 7],
+                                                     kt * 128, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 7],
+                                                     kt * 128, 0, 0);
+    };
+    bool pre = false;   // K-tile 0 of the tile about to start is already in flight (PF)
+    int64_t pm0 = 0, pn0 = 0;
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int64_t m0, n0;
+        if (pre) {
+            m0 = pm0; n0 = pn0;
+        } else {
+            int tile_m, tile_n;
+            tile_of_block(g, vb, tile_m, tile_n);
+            m0 = (int64_t)tile_m * BM; n0 = (int64_t)tile_n * BN;
+        }
+        TMARK(0);
         // ---- prologue: K-tiles 0 and 1 in flight, 0 readable; the 256 accumulator registers are zeroed while they land ----
+        if (!pre) {
+            set_offsets(m0, n0);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) dma(0, 0, p);
+            for (int p = 0; p < 16; ++p) dma(0, 0, p);
+        }
 #pragma unroll
         for (int p = 0; p < 16; ++p) dma(1, 1, p);
         __builtin_amdgcn_sched_barrier(0);
@@ -2066,14 +2082,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
         // ---- epilogue: both buffers are dead (every fragment read retired before barrier #1 of the last K-tile, no DMA in flight) ----
         TMARK(2);
         float part = 0.f;
-        float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+        pre = false;
+        if constexpr (PF) {
+            const int nvb = vb + (int)gridDim.x;
+            if (nvb < ntiles) {
+                int tile_m, tile_n;
+                tile_of_block(g, nvb, tile_m, tile_n);
+                pm0 = (int64_t)tile_m * BM; pn0 = (int64_t)tile_n * BN;
+                set_offsets(pm0, pn0);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) dma(0, 0, p);
+                pre = true;
+            }
+        }
+        char* park = smem + (PF ? TILE : 0);          // PF: the first buffer is filling
+        float* blk = reinterpret_cast<float*>(park) + wave * (32 * EPI_LD);
         // full in-bounds tile with the wide bf16 / 16-byte f32 access shapes -> unrolled double-buffered tail, else the generic one
         const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (OTTER_DIAG & (4 | 16)) == 0 &&
                           (g.cdt == OTTER_F32 || g.wide);
         if (full) {
-            float* blk2 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
-            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
-            else part = tail_wave_full<EPI, false>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
+            constexpr int NSP = PF ? 2 : TAIL_STRIPES;
+            float* blk2 = reinterpret_cast<float*>(park) + wave * (NSP * 32 * EPI_LD);
+            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true, NSP>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
+            else part = tail_wave_full<EPI, false, NSP>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
         } else {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -2098,7 +2129,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
             if (part == 12345.678f) reinterpret_cast<float*>(g.C)[threadIdx.x] = part;
         }
         TMARK(3);
-        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(park), vb);
         __syncthreads();  // the next tile's prologue DMA overwrites the stripes
         TMARK(4);
         ++tcount;
@@ -2201,7 +2232,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 int g_variant = 0;
 int g_debug = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_F32 = 100 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
@@ -2218,7 +2249,7 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
     if (v == CFG_WS && K % 64 != 0) v = CFG_256;
     const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB || v == CFG_PH2B || v == CFG_PHDB;
     if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
-    if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
+    if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C || v == CFG_R4P) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
     if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
@@ -2313,18 +2344,19 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
 #undef LAUNCH_MS
         return OTTER_OK;
     }
-    if (cfg == CFG_R4 || cfg == CFG_R4B || cfg == CFG_R4C) {
+    if (cfg == CFG_R4 || cfg == CFG_R4B || cfg == CFG_R4C || cfg == CFG_R4P) {
         const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;  // two K-tile buffers; the tail's parking buffers alias them
         unsigned pg = grid.x < 256u ? grid.x : 256u;
-#define LAUNCH_R4(SCH_)                                                                                                    \
+#define LAUNCH_R4(SCH_, PF_)                                                                                               \
     do {                                                                                                                   \
         static bool once = false;                                                                                          \
-        if (!once) { int rc = set_smem(gemm_bf16_r4_kernel<EPI, SCH_>, smem); if (rc) return rc; once = true; }            \
-        hipLaunchKernelGGL((gemm_bf16_r4_kernel<EPI, SCH_>), dim3(pg), dim3(256), smem, st, g);                            \
+        if (!once) { int rc = set_smem(gemm_bf16_r4_kernel<EPI, SCH_, PF_>, smem); if (rc) return rc; once = true; }       \
+        hipLaunchKernelGGL((gemm_bf16_r4_kernel<EPI, SCH_, PF_>), dim3(pg), dim3(256), smem, st, g);                       \
     } while (0)
-        if (cfg == CFG_R4) LAUNCH_R4(0);
-        else if (cfg == CFG_R4B) LAUNCH_R4(1);
-        else LAUNCH_R4(2);
+        if (cfg == CFG_R4) LAUNCH_R4(0, false);
+        else if (cfg == CFG_R4B) LAUNCH_R4(1, false);
+        else if (cfg == CFG_R4C) LAUNCH_R4(2, false);
+        else LAUNCH_R4(0, true);
 #undef LAUNCH_R4
         return OTTER_OK;
     }
@@ -2366,7 +2398,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 20) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 21) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }
