@@ -44,7 +44,7 @@ K.lib().otter_gemm_set_debug(0)
 buf = np.zeros(512, dtype=np.uint64)
 K.check(K.lib().otter_gemm_read_timeline(buf.ctypes.data_as(ctypes.c_void_p), 512), "timeline")
 t = buf.reshape(2, 4, 8, 8).astype(np.int64)
-ntile = (M // 256) * (N // 256) // 256
+ntile = max(1, (M // 256) * (N // 256) // 256)
 print("epilogue:", epi)
 for b in range(1):
     t0 = t[b, :, 0, 0].min()
