@@ -2059,6 +2059,140 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
         MMA(3, 2, 3); SB();                                                                                                                                                                     \
         MMA(3, 3, 3); SB();                                                                                                                                                                     \
     } while (0)
+#define KTILE_S3(BUF, TV, DMA, NEXT)                                                                                         \
+    do {                                                                                                                     \
+        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                       \
+        MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                       \
+        MMA(0, 0, 1); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                       \
+        MMA(0, 1, 1); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                       \
+        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                       \
+        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB();                                                       \
+        MMA(0, 3, 0); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                       \
+        MMA(0, 3, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                       \
+        MMA(0, 0, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                       \
+        MMA(0, 1, 2); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB();                                                       \
+        MMA(0, 2, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                       \
+        MMA(0, 3, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                       \
+        MMA(0, 0, 3); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                       \
+        MMA(0, 1, 3); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB();                                                       \
+        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                       \
+        MMA(0, 3, 3); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                       \
+        MMA(1, 0, 0); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB();                                                       \
+        MMA(1, 1, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                       \
+        MMA(1, 0, 1); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB();                                                       \
+        MMA(1, 1, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                       \
+        MMA(1, 2, 0); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB();                                                       \
+        MMA(1, 2, 1); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                       \
+        MMA(1, 3, 0); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB();                                                       \
+        MMA(1, 3, 1); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                       \
+        MMA(1, 0, 2); SB();                                                                                                  \
+        MMA(1, 1, 2); SB();                                                                                                  \
+        MMA(1, 2, 2); SB();                                                                                                  \
+        MMA(1, 3, 2); SB(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();  \
+        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                            \
+        MMA(1, 1, 3); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
+        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                            \
+        MMA(1, 3, 3); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
+        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                            \
+        MMA(2, 1, 0); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
+        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                            \
+        MMA(2, 1, 1); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
+        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                            \
+        MMA(2, 2, 1); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
+        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                            \
+        MMA(2, 3, 1); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
+        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                            \
+        MMA(2, 1, 2); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
+        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                            \
+        MMA(2, 3, 2); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
+        MMA(2, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                            \
+        MMA(2, 1, 3); SB();                                                                                                  \
+        MMA(2, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                            \
+        MMA(2, 3, 3); SB();                                                                                                  \
+        MMA(3, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                           \
+        MMA(3, 1, 0); SB();                                                                                                  \
+        MMA(3, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                           \
+        MMA(3, 1, 1); SB();                                                                                                  \
+        MMA(3, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                           \
+        MMA(3, 2, 1); SB();                                                                                                  \
+        MMA(3, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                           \
+        MMA(3, 3, 1); SB();                                                                                                  \
+        MMA(3, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                           \
+        MMA(3, 1, 2); SB();                                                                                                  \
+        MMA(3, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                           \
+        MMA(3, 3, 2); SB();                                                                                                  \
+        MMA(3, 0, 3); SB();                                                                                                  \
+        MMA(3, 1, 3); SB();                                                                                                  \
+        MMA(3, 2, 3); SB();                                                                                                  \
+        MMA(3, 3, 3); SB();                                                                                                  \
+    } while (0)
+#define KTILE_S4(BUF, TV, DMA, NEXT)                                                                                         \
+    do {                                                                                                                     \
+        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                       \
+        MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                       \
+        MMA(0, 0, 1); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                       \
+        MMA(0, 1, 1); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                       \
+        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                       \
+        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB();                                                       \
+        MMA(0, 3, 0); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                       \
+        MMA(0, 3, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                       \
+        MMA(0, 0, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                       \
+        MMA(0, 1, 2); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB();                                                       \
+        MMA(0, 2, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                       \
+        MMA(0, 3, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                       \
+        MMA(0, 0, 3); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                       \
+        MMA(0, 1, 3); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB();                                                       \
+        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                       \
+        MMA(0, 3, 3); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                       \
+        MMA(1, 0, 0); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB();                                                       \
+        MMA(1, 1, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                       \
+        MMA(1, 0, 1); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB();                                                       \
+        MMA(1, 1, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                       \
+        MMA(1, 2, 0); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB();                                                       \
+        MMA(1, 2, 1); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                       \
+        MMA(1, 3, 0); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB();                                                       \
+        MMA(1, 3, 1); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                       \
+        MMA(1, 0, 2); SB();                                                                                                  \
+        MMA(1, 1, 2); SB();                                                                                                  \
+        MMA(1, 2, 2); SB();                                                                                                  \
+        MMA(1, 3, 2); SB(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();  \
+        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                            \
+        MMA(1, 1, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                            \
+        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                            \
+        MMA(1, 3, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                            \
+        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                            \
+        MMA(2, 1, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                            \
+        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                            \
+        MMA(2, 1, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                            \
+        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                            \
+        MMA(2, 2, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                            \
+        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                           \
+        MMA(2, 3, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                           \
+        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                           \
+        MMA(2, 1, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                           \
+        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                           \
+        MMA(2, 3, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                           \
+        MMA(2, 0, 3); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
+        MMA(2, 1, 3); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
+        MMA(2, 2, 3); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
+        MMA(2, 3, 3); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
+        MMA(3, 0, 0); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
+        MMA(3, 1, 0); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
+        MMA(3, 0, 1); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
+        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
+        MMA(3, 2, 0); SB();                                                                                                  \
+        MMA(3, 2, 1); SB();                                                                                                  \
+        MMA(3, 3, 0); SB();                                                                                                  \
+        MMA(3, 3, 1); SB();                                                                                                  \
+        MMA(3, 0, 2); SB();                                                                                                  \
+        MMA(3, 1, 2); SB();                                                                                                  \
+        MMA(3, 2, 2); SB();                                                                                                  \
+        MMA(3, 3, 2); SB();                                                                                                  \
+        MMA(3, 0, 3); SB();                                                                                                  \
+        MMA(3, 1, 3); SB();                                                                                                  \
+        MMA(3, 2, 3); SB();                                                                                                  \
+        MMA(3, 3, 3); SB();                                                                                                  \
+    } while (0)
 // ---- end of generated schedule ----
 #define KLOOP(KT)                                   \
     do {                                            \
@@ -2072,11 +2206,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
     } while (0)
         if constexpr (SCH == 0) KLOOP(KTILE_S0);
         else if constexpr (SCH == 1) KLOOP(KTILE_S1);
-        else KLOOP(KTILE_S2);
+        else if constexpr (SCH == 2) KLOOP(KTILE_S2);
+        else if constexpr (SCH == 3) KLOOP(KTILE_S3);
+        else KLOOP(KTILE_S4);
 #undef KLOOP
 #undef KTILE_S0
 #undef KTILE_S1
 #undef KTILE_S2
+#undef KTILE_S3
+#undef KTILE_S4
 #undef MMA
 
         // ---- epilogue: both buffers are dead (every fragment read retired before barrier #1 of the last K-tile, no DMA in flight) ----
@@ -2232,7 +2370,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 int g_variant = 0;
 int g_debug = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_F32 = 100 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
@@ -2249,7 +2387,7 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
     if (v == CFG_WS && K % 64 != 0) v = CFG_256;
     const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB || v == CFG_PH2B || v == CFG_PHDB;
     if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
-    if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C || v == CFG_R4P) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
+    if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C || v == CFG_R4P || v == CFG_R4M || v == CFG_R4N) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
     if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
@@ -2344,7 +2482,7 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
 #undef LAUNCH_MS
         return OTTER_OK;
     }
-    if (cfg == CFG_R4 || cfg == CFG_R4B || cfg == CFG_R4C || cfg == CFG_R4P) {
+    if (cfg == CFG_R4 || cfg == CFG_R4B || cfg == CFG_R4C || cfg == CFG_R4P || cfg == CFG_R4M || cfg == CFG_R4N) {
         const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;  // two K-tile buffers; the tail's parking buffers alias them
         unsigned pg = grid.x < 256u ? grid.x : 256u;
 #define LAUNCH_R4(SCH_, PF_)                                                                                               \
@@ -2356,6 +2494,8 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         if (cfg == CFG_R4) LAUNCH_R4(0, false);
         else if (cfg == CFG_R4B) LAUNCH_R4(1, false);
         else if (cfg == CFG_R4C) LAUNCH_R4(2, false);
+        else if (cfg == CFG_R4M) LAUNCH_R4(3, false);
+        else if (cfg == CFG_R4N) LAUNCH_R4(4, false);
         else LAUNCH_R4(0, true);
 #undef LAUNCH_R4
         return OTTER_OK;
@@ -2398,7 +2538,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 21) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 23) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }
