@@ -208,3 +208,26 @@ def test_tokenizer_fallback_is_explicit(monkeypatch):
         MO._load_tokenizer("mosaicml/mpt-7b-instruct", 50432)
     monkeypatch.setenv("OTTER_STUB_TOKENIZER", "1")
     assert isinstance(MO._load_tokenizer("mosaicml/mpt-7b-instruct", 50432), MO.OtterStubTokenizer)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import it.  No module
+    of the product package does (directly or through the fixture generators), and bench.py touches it inside cpu_baseline only."""
+    import ast
+    import glob
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in sorted(glob.glob(os.path.join(root, "otter_amd", "**", "*.py"), recursive=True)):
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), (path, names)
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and ("oracle" in ((getattr(n, "module", None) or "") + " ".join(a.name for a in n.names)))
+                   for n in ast.walk(fn))
+        assert (not uses) or fn.name == "cpu_baseline", fn.name
