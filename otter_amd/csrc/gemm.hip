@@ -16,6 +16,7 @@
 //     chunk of that order, so a weight panel is fetched into one XCD's L2 once.
 // f32 kernel (parity mode, exact f32): v_mfma_f32_32x32x2_f32, 64x64x32 tile, padded LDS rows.
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -2278,6 +2279,188 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// bf16 small-grid kernel (variant 25): 128x128 tile, 4 waves of 64x64, BK = 64 stages in a 4-deep LDS-DMA ring.
+// Why: the gated block's and the perceiver's projections with N or M = 512 are at most 128-256 tiles -- one block per CU at
+// best -- with a LONG reduction (K = 4096): the register-staged double buffer of gemm_bf16_kernel<128,128> pays one global
+// latency per K-tile there (66-76 us against 19-27 us for hipBLASLt on 4096x512x4096 / 512x4096x4096 / 512x1024x4096,
+// tools/gemm_small.py), and a smaller tile (64x128: all 256 CUs busy) changes nothing (74 us) -- it is latency, not occupancy.
+// So: the ring + counted-vmcnt pipeline of variant 17 on a 128x128 tile with the 128-byte-row LDS image: the DMA of stage s+3
+// is issued during step s (three K-tiles of prefetch, ~2.5 us to land), one raw barrier per K-tile, slots pinned (one fragment
+// read per MFMA slot, a DMA piece on every other one).  Schedule generated by tools/gen/gemm_s4_schedule.py.
+// Requires K % 256 == 0 (four stages per unrolled trip) and operands spanning < 4 GB.
+// ------------------------------------------------------------------------------------------------------------
+template <int EPI, bool CBF16>
+__device__ __forceinline__ float tail_wave2_full(const GemmArgs& g, float s, const f32x16_t (&acc)[2][2], float* __restrict__ blk2, int64_t m_wave,
+                                                 int64_t n_wave, int lane) {
+    using T = TailShape<CBF16>;
+    const void* ip; int64_t ild; int idt;
+    const bool has_in = tail_input<EPI>(g, ip, ild, idt);
+    float part = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        park_block(blk2 + mi * (32 * EPI_LD), acc[mi][0], lane, 0);
+        park_block(blk2 + mi * (32 * EPI_LD), acc[mi][1], lane, 32);
+    }
+    __builtin_amdgcn_wave_barrier();
+    auto run = [&](auto inbf) {
+        constexpr bool INBF16 = decltype(inbf)::value;
+        uint4 r0[T::NIT][2], r1[T::NIT][2];
+        if (has_in) {
+            tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave, lane, r0);
+            tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + 32, n_wave, lane, r1);
+        }
+        part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk2, m_wave, n_wave, lane, r0, has_in);
+        part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk2 + 32 * EPI_LD, m_wave + 32, n_wave, lane, r1, has_in);
+    };
+    if (EPI == OTTER_EPI_GELU || idt == OTTER_BF16) run(std::true_type{});
+    else run(std::false_type{});
+    __builtin_amdgcn_wave_barrier();
+    return part;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_s4_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 128, NT = 256;
+    constexpr int STAGE = (BM + BN) * 128;  // 32 KB: [128 A rows ; 128 B rows] x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
+    const int nk = (int)(g.K >> 6);  // stages (host guarantees nk % 4 == 0, nk >= 4)
+    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
+    // fragment read bases per k-step (row = w*64 + i*32 + (lane&31), slot (2*ks + (lane>>5)) ^ ((row>>1)&7)); ring slots 0/1 through the
+    // ds_read immediate, slots 2/3 (+64 KB) through their own registers
+    const int swz = ((lane & 31) >> 1) & 7;
+    int ra[4], rb[4], ra_hi[4], rb_hi[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int slot = (2 * ks + (lane >> 5)) ^ swz;
+        ra[ks] = (wm * 64 + (lane & 31)) * 128 + (slot << 4);
+        rb[ks] = BM * 128 + (wn * 64 + (lane & 31)) * 128 + (slot << 4);
+        ra_hi[ks] = ra[ks] + 2 * STAGE;
+        rb_hi[ks] = rb[ks] + 2 * STAGE;
+        asm volatile("" : "+v"(ra_hi[ks]), "+v"(rb_hi[ks]));
+    }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define LDF(dst, base, S_, KS, I)                                                                                          \
+    dst = *reinterpret_cast<const bf16x8_t*>(smem + ((S_) < 2 ? base[KS] + (S_) * STAGE : base##_hi[KS] + ((S_) - 2) * STAGE) + (I) * 4096)
+
+    const int ntiles = g.gm * g.gn;
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int tile_m, tile_n;
+        tile_of_block(g, vb, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+        uint32_t oa[4], ob[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+            const int slot = phys ^ ((row >> 1) & 7);
+            int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
+            int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
+            oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
+            ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
+        }
+        // piece p (0..3 = A, 4..7 = B) of the stage holding K columns [step*64, +64) into ring slot S_
+        auto dma = [&](int S_, int step, int p) {
+            const int wbase = S_ * STAGE + (p >> 2) * (BM * 128) + ((p & 3) * NT + wave * 64) * 16;
+            if (p < 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p & 3],
+                                                         step * 128, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 3],
+                                                         step * 128, 0, 0);
+        };
+        // ---- prologue: stages 0..2 in flight, 0 and 1 readable ----
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) dma(st, st, p);
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8_t fm[4][2], fn[4][2];  // [k-step][32-row block]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            LDF(fn[0][i], rb, 0, 0, i);
+            LDF(fm[0][i], ra, 0, 0, i);
+        }
+#define MMA(KS, MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0)
+// ---- GENERATED by tools/gen/gemm_s4_schedule.py (do not edit by hand) ----
+#define KSTEP(S, STEPV, DMA, NEXT, VMW)                                                                               \
+    do {                                                                                                              \
+        constexpr int SN = ((S) + 1) & 3, SD = ((S) + 3) & 3;                                                       \
+        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, S, 1, 0); SB();                                                         \
+        MMA(0, 1, 0); SB(); LDF(fm[1][0], ra, S, 1, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 0); SB();                 \
+        MMA(0, 0, 1); SB(); LDF(fm[1][1], ra, S, 1, 1); SB();                                                         \
+        MMA(0, 1, 1); SB(); LDF(fn[1][1], rb, S, 1, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 1); SB();                 \
+        MMA(1, 0, 0); SB(); LDF(fn[2][0], rb, S, 2, 0); SB();                                                         \
+        MMA(1, 1, 0); SB(); LDF(fm[2][0], ra, S, 2, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 2); SB();                 \
+        MMA(1, 0, 1); SB(); LDF(fm[2][1], ra, S, 2, 1); SB();                                                         \
+        MMA(1, 1, 1); SB(); LDF(fn[2][1], rb, S, 2, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 3); SB();                 \
+        MMA(2, 0, 0); SB(); LDF(fn[3][0], rb, S, 3, 0); SB();                                                         \
+        MMA(2, 1, 0); SB(); LDF(fm[3][0], ra, S, 3, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 4); SB();                 \
+        MMA(2, 0, 1); SB(); LDF(fm[3][1], ra, S, 3, 1); SB();                                                         \
+        MMA(2, 1, 1); SB(); LDF(fn[3][1], rb, S, 3, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 5); SB();                 \
+        MMA(3, 0, 0); SB(); if (NEXT) { LDF(fn[0][0], rb, SN, 0, 0); } SB();                                          \
+        MMA(3, 1, 0); SB(); if (NEXT) { LDF(fm[0][0], ra, SN, 0, 0); } SB(); if (DMA) dma(SD, (STEPV) + 3, 6); SB();  \
+        MMA(3, 0, 1); SB(); if (NEXT) { LDF(fm[0][1], ra, SN, 0, 1); } SB();                                          \
+        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fn[0][1], rb, SN, 0, 1); } SB(); if (DMA) dma(SD, (STEPV) + 3, 7); SB();  \
+        asm volatile("s_waitcnt vmcnt(" #VMW ")" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                   \
+    } while (0)
+// ---- end of generated schedule ----
+        int st = 0;
+        for (; st + 4 < nk; st += 4) {   // full trips: every step issues its stage st+3
+            KSTEP(0, st, true, true, 8);
+            KSTEP(1, st + 1, true, true, 8);
+            KSTEP(2, st + 2, true, true, 8);
+            KSTEP(3, st + 3, true, true, 8);
+        }
+        KSTEP(0, st, true, true, 8);      // last trip: stage nk-1 is issued by its first step, then the queue drains
+        KSTEP(1, st + 1, false, true, 0);
+        KSTEP(2, st + 2, false, true, 0);
+        KSTEP(3, st + 3, false, false, 0);
+#undef KSTEP
+#undef MMA
+
+        // ---- epilogue: the ring is free (every DMA retired, every wave past the last barrier, every fragment read consumed) ----
+        float part = 0.f;
+        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (g.cdt == OTTER_F32 || g.wide);
+        if (full) {
+            float* blk2 = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPI_LD);
+            if (g.cdt == OTTER_BF16) part = tail_wave2_full<EPI, true>(g, sgate, acc, blk2, m0 + wm * 64, n0 + wn * 64, lane);
+            else part = tail_wave2_full<EPI, false>(g, sgate, acc, blk2, m0 + wm * 64, n0 + wn * 64, lane);
+        } else {
+            float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                park_block(blk, acc[mi][0], lane, 0);
+                park_block(blk, acc[mi][1], lane, 32);
+                __builtin_amdgcn_wave_barrier();
+                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 64 + mi * 32, n0 + wn * 64, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+        __syncthreads();  // the next tile's prologue DMA overwrites the stripes
+    }
+#undef LDF
+#undef SB
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // exact-f32 MFMA kernel (parity mode): 64x64x32 tile, 4 waves (2x2), one 32x32 accumulator block per wave
 // ------------------------------------------------------------------------------------------------------------
 template <int EPI>
@@ -2370,7 +2553,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 int g_variant = 0;
 int g_debug = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_F32 = 100 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_S4 = 25, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
@@ -2381,6 +2564,7 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
         // register-resident K-tile (variant 18) beats round 1's balanced 8-wave phased schedule (variant 13) on all three
         // FFN shapes (1.29 / 1.49 / 1.43 PF vs 1.19 / 1.39 / 1.37 on one box); it needs K % 128 == 0, else 13 stays
         if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = (K % 128 == 0 && !wide) ? CFG_R4 : CFG_PHLB;
+        else if (K % 256 == 0 && K >= 1024 && !wide && cdiv64(M, 128) * cdiv64(N, 128) <= 512) v = CFG_S4;   // few tiles, long reduction: the ring
         else v = CFG_128;
     }
     if ((v == CFG_MS4 || v == CFG_MS5 || v == CFG_MS5B) && (K % 32 != 0)) v = CFG_256_GLDS;
@@ -2388,13 +2572,14 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
     const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB || v == CFG_PH2B || v == CFG_PHDB;
     if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
     if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C || v == CFG_R4P || v == CFG_R4M || v == CFG_R4N) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
+    if (v == CFG_S4 && (K % 256 != 0 || wide)) v = CFG_128;
     if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
 }
 void cfg_tiles(int cfg, int& bm, int& bn) {
     if (cfg == CFG_F32) { bm = 64; bn = 64; }
-    else if (cfg == CFG_128) { bm = 128; bn = 128; }
+    else if (cfg == CFG_128 || cfg == CFG_S4) { bm = 128; bn = 128; }
     else { bm = 256; bn = 256; }
 }
 
@@ -2500,6 +2685,14 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
 #undef LAUNCH_R4
         return OTTER_OK;
     }
+    if (cfg == CFG_S4) {
+        static bool once = false;
+        const int smem = 4 * 32768;  // the ring; the tail's parking buffers (4 waves x 2 stripes = 69632 B) alias it
+        if (!once) { int rc = set_smem(gemm_bf16_s4_kernel<EPI>, smem); if (rc) return rc; once = true; }
+        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        hipLaunchKernelGGL((gemm_bf16_s4_kernel<EPI>), dim3(pg), dim3(256), smem, st, g);
+        return OTTER_OK;
+    }
     if (cfg == CFG_Q4) {
         static bool once = false;
         const int smem = TAIL_LDS_BYTES;  // 4 x 32 KB ring; the tail's parking buffers (139264 B) alias it
@@ -2538,7 +2731,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 23) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 25) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }
