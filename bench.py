@@ -330,8 +330,9 @@ def main():
             # HBM-side traffic per launch comes from the separate rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
             # WRITE_SIZE) committed under profiles/; PMC collection cannot share a run with the timed region.
             traffic = None
-            v = args.gemm_variant or 18
-            names = {13: "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves, phased)", 18: "gemm_bf16_r4_kernel (256x256x64 tile, 4 waves, register-resident K-tile)"}
+            v = args.gemm_variant or 26
+            names = {13: "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves, phased)", 18: "gemm_bf16_r4_kernel (256x256x64 tile, 4 waves, register-resident K-tile)",
+                     26: "gemm_bf16_t4_kernel (256x256x64 tile, 4 waves, register-resident K-tile, 16x16x32 MFMA)"}
             pmc = os.path.join(ROOT, "profiles", "r02_pmc_gemm_ffn_v18.json" if v == 18 else "r01_pmc_gemm_ffn_v13.json")
             if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
                 with open(pmc) as f:

@@ -17,6 +17,7 @@
 // f32 kernel (parity mode, exact f32): v_mfma_f32_32x32x2_f32, 64x64x32 tile, padded LDS rows.
 #include "common.h"
 #include <type_traits>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -462,8 +463,24 @@ __device__ __forceinline__ float tail_stripe_full(GemmArgs g, float s, const flo
 constexpr int TAIL_STRIPES = 4;
 constexpr int TAIL_LDS_BYTES = 4 * TAIL_STRIPES * 32 * EPI_LD * 4;  // 4 waves: 139264 B
 
-template <int EPI, bool CBF16, bool INBF16, int NS>
-__device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4 /* NS stripes */,
+// stripe st (0..7) of a 128x128 wave tile = rows 32*(st>>1).., columns 64*(st&1)..; the two accumulator layouts park it differently
+__device__ __forceinline__ void park_stripe(float* __restrict__ blk, const f32x16_t (&acc)[4][4], int st, int lane) {
+    park_block(blk, acc[st >> 1][2 * (st & 1)], lane, 0);
+    park_block(blk, acc[st >> 1][2 * (st & 1) + 1], lane, 32);
+}
+// 16x16 blocks (v_mfma_f32_16x16x32 with the operands swapped): lane holds row m = lane&15 of the block, columns 4*(lane>>4) + 0..3
+__device__ __forceinline__ void park_stripe(float* __restrict__ blk, const f32x4_t (&acc)[8][8], int st, int lane) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x4_t& v = acc[2 * (st >> 1) + a][4 * (st & 1) + b];
+            *reinterpret_cast<float4*>(blk + (16 * a + (lane & 15)) * EPI_LD + 16 * b + 4 * (lane >> 4)) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+}
+
+template <int EPI, bool CBF16, bool INBF16, int NS, typename ACC>
+__device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, const ACC& acc, float* __restrict__ blk4 /* NS stripes */,
                                                   int64_t m_wave, int64_t n_wave, int lane, const void* ip, int64_t ild, bool has_in) {
     using T = TailShape<CBF16>;
     float part = 0.f;
@@ -474,8 +491,7 @@ __device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, co
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
             const int st = half * NS + q;
-            park_block(blk4 + q * (32 * EPI_LD), acc[st >> 1][2 * (st & 1)], lane, 0);
-            park_block(blk4 + q * (32 * EPI_LD), acc[st >> 1][2 * (st & 1) + 1], lane, 32);
+            park_stripe(blk4 + q * (32 * EPI_LD), acc, st, lane);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -493,8 +509,8 @@ __device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, co
     return part;
 }
 
-template <int EPI, bool CBF16, int NS = TAIL_STRIPES>
-__device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const f32x16_t (&acc)[4][4], float* __restrict__ blk4, int64_t m_wave,
+template <int EPI, bool CBF16, int NS = TAIL_STRIPES, typename ACC>
+__device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, const ACC& acc, float* __restrict__ blk4, int64_t m_wave,
                                                 int64_t n_wave, int lane) {
     const void* ip; int64_t ild; int idt;
     const bool has_in = tail_input<EPI>(g, ip, ild, idt);
@@ -2279,6 +2295,681 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// bf16 register-resident K-tile kernel on v_mfma_f32_16x16x32_bf16 (variant 26): variant 18's pipeline, LDS image and DMA
+// unchanged, the matrix instruction swapped.  Why: tools/probe/mfma_power.hip -- back-to-back MFMAs, one wave per SIMD, 256
+// accumulator registers, N(0, 0.05) bf16 operands -- sustains 1.81 PF with 32x32x16 (1.72 GHz under the power cap) and
+// 2.07 PF with 16x16x32 (1.97 GHz); with zero operands both run at 2.47 PF (2.35 GHz).  The 16x16x32 shape reads and writes
+// its accumulator half as often per flop (k = 32 per pass over a 4-register block against k = 16 over a 16-register block),
+// and on real data the GEMM is clock-bound by power, not issue-bound: hipBLASLt's gfx950 kernels use MI16x16 as well.
+// Wave tile 128x128 = 8 x 8 blocks of 16x16 (f32x4 each), K-tile = 2 k-steps x 64 MFMAs of 16 cycles; fragment of block i,
+// k-step ks: row i*16 + (lane&15), 16-byte slot (4*ks + (lane>>4)) ^ ((row>>1)&7) -- 16 lanes of a quarter-wave hit 8 slots x 2
+// row parities = 16 distinct bank groups with the same swizzle as the 32-row fragments.
+// Schedule generated by tools/gen/gemm_t4_schedule.py.  Requires K % 128 == 0 and operands spanning < 4 GB.
+// ------------------------------------------------------------------------------------------------------------
+template <int EPI, int SCH>
+__global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, NT = 256;
+    constexpr int TILE = (BM + BN) * 128;  // 64 KB: [256 A rows ; 256 B rows] x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
+    const int nk = (int)(g.K >> 6);  // K-tiles (host guarantees nk even, nk >= 2)
+    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
+    const int swz = (lane & 15) >> 1;
+    int ra[2], rb[2], ra_hi[2], rb_hi[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int slot = (4 * ks + (lane >> 4)) ^ swz;
+        ra[ks] = (wm * 128 + (lane & 15)) * 128 + (slot << 4);
+        rb[ks] = BM * 128 + (wn * 128 + (lane & 15)) * 128 + (slot << 4);
+        ra_hi[ks] = ra[ks] + TILE;
+        rb_hi[ks] = rb[ks] + TILE;
+        asm volatile("" : "+v"(ra_hi[ks]), "+v"(rb_hi[ks]));
+    }
+#define TMARK(K_)                                                                                                         \
+    do {                                                                                                                  \
+        if ((g.dbg & 64) && (blockIdx.x == 0 || blockIdx.x == 131) && lane == 0 && tcount < 8)                            \
+            g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + (K_)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+    int tcount = 0;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define LDF(dst, base_lo, base_hi, BUFV, KS, I) dst = *reinterpret_cast<const bf16x8_t*>(smem + (((BUFV) & 1) ? base_hi[KS] : base_lo[KS]) + (I) * 2048)
+
+    const int ntiles = g.gm * g.gn;
+    uint32_t oa[8], ob[8];
+    // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
+    auto dma = [&](int bufv, int kt, int p) {
+        const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
+        if (p < 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p & 7],
+                                                     kt * 128, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 7],
+                                                     kt * 128, 0, 0);
+    };
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int tile_m, tile_n;
+        tile_of_block(g, vb, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+        TMARK(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+            const int slot = phys ^ ((row >> 1) & 7);
+            int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
+            int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
+            oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
+            ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
+        }
+        // ---- prologue: K-tiles 0 and 1 in flight, 0 readable; the 256 accumulator registers are zeroed while they land ----
+#pragma unroll
+        for (int p = 0; p < 16; ++p) dma(0, 0, p);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) dma(1, 1, p);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_t acc[8][8];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8_t fm[2][8], fn[2][8];  // [k-step][16-row block]: fm = A rows (b-operand), fn = B rows (a-operand)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            LDF(fm[0][i], ra, ra_hi, 0, 0, i);
+            LDF(fn[0][i], rb, rb_hi, 0, 0, i);
+        }
+        TMARK(1);
+#define MMA(KS, MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0)
+// ---- GENERATED by tools/gen/gemm_t4_schedule.py (do not edit by hand) ----
+#define KTILE_T0(BUF, TV, DMA, NEXT)                                                                                                                                                            \
+    do {                                                                                                                                                                                        \
+        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 1, 0); SB();                                                                                                                                                                     \
+        MMA(0, 0, 1); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 1, 1); SB();                                                                                                                                                                     \
+        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 2, 1); SB();                                                                                                                                                                     \
+        MMA(0, 0, 2); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 1, 2); SB();                                                                                                                                                                     \
+        MMA(0, 2, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 3, 0); SB();                                                                                                                                                                     \
+        MMA(0, 3, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 3, 2); SB();                                                                                                                                                                     \
+        MMA(0, 0, 3); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 1, 3); SB();                                                                                                                                                                     \
+        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 3, 3); SB();                                                                                                                                                                     \
+        MMA(0, 4, 0); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                          \
+        MMA(0, 4, 1); SB();                                                                                                                                                                     \
+        MMA(0, 4, 2); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                          \
+        MMA(0, 4, 3); SB();                                                                                                                                                                     \
+        MMA(0, 0, 4); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                          \
+        MMA(0, 1, 4); SB();                                                                                                                                                                     \
+        MMA(0, 2, 4); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                          \
+        MMA(0, 3, 4); SB();                                                                                                                                                                     \
+        MMA(0, 4, 4); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                          \
+        MMA(0, 5, 0); SB();                                                                                                                                                                     \
+        MMA(0, 5, 1); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                          \
+        MMA(0, 5, 2); SB();                                                                                                                                                                     \
+        MMA(0, 5, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                          \
+        MMA(0, 5, 4); SB();                                                                                                                                                                     \
+        MMA(0, 0, 5); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                          \
+        MMA(0, 1, 5); SB();                                                                                                                                                                     \
+        MMA(0, 2, 5); SB();                                                                                                                                                                     \
+        MMA(0, 3, 5); SB();                                                                                                                                                                     \
+        MMA(0, 4, 5); SB();                                                                                                                                                                     \
+        MMA(0, 5, 5); SB();                                                                                                                                                                     \
+        MMA(0, 6, 0); SB();                                                                                                                                                                     \
+        MMA(0, 6, 1); SB();                                                                                                                                                                     \
+        MMA(0, 6, 2); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
+        MMA(0, 6, 3); SB();                                                                                                                                                                     \
+        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
+        MMA(0, 6, 5); SB();                                                                                                                                                                     \
+        MMA(0, 0, 6); SB();                                                                                                                                                                     \
+        MMA(0, 1, 6); SB();                                                                                                                                                                     \
+        MMA(0, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
+        MMA(0, 3, 6); SB();                                                                                                                                                                     \
+        MMA(0, 4, 6); SB();                                                                                                                                                                     \
+        MMA(0, 5, 6); SB();                                                                                                                                                                     \
+        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
+        MMA(0, 7, 0); SB();                                                                                                                                                                     \
+        MMA(0, 7, 1); SB();                                                                                                                                                                     \
+        MMA(0, 7, 2); SB();                                                                                                                                                                     \
+        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
+        MMA(0, 7, 4); SB();                                                                                                                                                                     \
+        MMA(0, 7, 5); SB();                                                                                                                                                                     \
+        MMA(0, 7, 6); SB();                                                                                                                                                                     \
+        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
+        MMA(0, 1, 7); SB();                                                                                                                                                                     \
+        MMA(0, 2, 7); SB();                                                                                                                                                                     \
+        MMA(0, 3, 7); SB();                                                                                                                                                                     \
+        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
+        MMA(0, 5, 7); SB();                                                                                                                                                                     \
+        MMA(0, 6, 7); SB();                                                                                                                                                                     \
+        MMA(0, 7, 7); SB();                                                                                                                                                                     \
+        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
+        MMA(1, 1, 0); SB();                                                                                                                                                                     \
+        MMA(1, 0, 1); SB();                                                                                                                                                                     \
+        MMA(1, 1, 1); SB();                                                                                                                                                                     \
+        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
+        MMA(1, 2, 1); SB();                                                                                                                                                                     \
+        MMA(1, 0, 2); SB();                                                                                                                                                                     \
+        MMA(1, 1, 2); SB();                                                                                                                                                                     \
+        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
+        MMA(1, 3, 0); SB();                                                                                                                                                                     \
+        MMA(1, 3, 1); SB();                                                                                                                                                                     \
+        MMA(1, 3, 2); SB();                                                                                                                                                                     \
+        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
+        MMA(1, 1, 3); SB();                                                                                                                                                                     \
+        MMA(1, 2, 3); SB();                                                                                                                                                                     \
+        MMA(1, 3, 3); SB();                                                                                                                                                                     \
+        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
+        MMA(1, 4, 1); SB();                                                                                                                                                                     \
+        MMA(1, 4, 2); SB();                                                                                                                                                                     \
+        MMA(1, 4, 3); SB();                                                                                                                                                                     \
+        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
+        MMA(1, 1, 4); SB();                                                                                                                                                                     \
+        MMA(1, 2, 4); SB();                                                                                                                                                                     \
+        MMA(1, 3, 4); SB();                                                                                                                                                                     \
+        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
+        MMA(1, 5, 0); SB();                                                                                                                                                                     \
+        MMA(1, 5, 1); SB();                                                                                                                                                                     \
+        MMA(1, 5, 2); SB();                                                                                                                                                                     \
+        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
+        MMA(1, 5, 4); SB();                                                                                                                                                                     \
+        MMA(1, 0, 5); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
+        MMA(1, 1, 5); SB();                                                                                                                                                                     \
+        MMA(1, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
+        MMA(1, 3, 5); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
+        MMA(1, 4, 5); SB();                                                                                                                                                                     \
+        MMA(1, 5, 5); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
+        MMA(1, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
+        MMA(1, 6, 1); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
+        MMA(1, 6, 2); SB();                                                                                                                                                                     \
+        MMA(1, 6, 3); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
+        MMA(1, 6, 4); SB();                                                                                                                                                                     \
+        MMA(1, 6, 5); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
+        MMA(1, 0, 6); SB();                                                                                                                                                                     \
+        MMA(1, 1, 6); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
+        MMA(1, 2, 6); SB();                                                                                                                                                                     \
+        MMA(1, 3, 6); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
+        MMA(1, 4, 6); SB();                                                                                                                                                                     \
+        MMA(1, 5, 6); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
+        MMA(1, 6, 6); SB();                                                                                                                                                                     \
+        MMA(1, 7, 0); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
+        MMA(1, 7, 1); SB();                                                                                                                                                                     \
+        MMA(1, 7, 2); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
+        MMA(1, 7, 3); SB();                                                                                                                                                                     \
+        MMA(1, 7, 4); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
+        MMA(1, 7, 5); SB();                                                                                                                                                                     \
+        MMA(1, 7, 6); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
+        MMA(1, 0, 7); SB();                                                                                                                                                                     \
+        MMA(1, 1, 7); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
+        MMA(1, 2, 7); SB();                                                                                                                                                                     \
+        MMA(1, 3, 7); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
+        MMA(1, 4, 7); SB();                                                                                                                                                                     \
+        MMA(1, 5, 7); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+        MMA(1, 6, 7); SB();                                                                                                                                                                     \
+        MMA(1, 7, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+    } while (0)
+#define KTILE_T1(BUF, TV, DMA, NEXT)                                                                                                                                                            \
+    do {                                                                                                                                                                                        \
+        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 1, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 0, 1); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 1, 1); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 2, 0); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 2, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 0, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 1, 2); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 2, 2); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                          \
+        MMA(0, 3, 0); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                          \
+        MMA(0, 3, 1); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                          \
+        MMA(0, 3, 2); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                          \
+        MMA(0, 0, 3); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                          \
+        MMA(0, 1, 3); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                          \
+        MMA(0, 2, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                          \
+        MMA(0, 3, 3); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                          \
+        MMA(0, 4, 0); SB();                                                                                                                                                                     \
+        MMA(0, 4, 1); SB();                                                                                                                                                                     \
+        MMA(0, 4, 2); SB();                                                                                                                                                                     \
+        MMA(0, 4, 3); SB();                                                                                                                                                                     \
+        MMA(0, 0, 4); SB();                                                                                                                                                                     \
+        MMA(0, 1, 4); SB();                                                                                                                                                                     \
+        MMA(0, 2, 4); SB();                                                                                                                                                                     \
+        MMA(0, 3, 4); SB();                                                                                                                                                                     \
+        MMA(0, 4, 4); SB();                                                                                                                                                                     \
+        MMA(0, 5, 0); SB();                                                                                                                                                                     \
+        MMA(0, 5, 1); SB();                                                                                                                                                                     \
+        MMA(0, 5, 2); SB();                                                                                                                                                                     \
+        MMA(0, 5, 3); SB();                                                                                                                                                                     \
+        MMA(0, 5, 4); SB();                                                                                                                                                                     \
+        MMA(0, 0, 5); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
+        MMA(0, 1, 5); SB();                                                                                                                                                                     \
+        MMA(0, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
+        MMA(0, 3, 5); SB();                                                                                                                                                                     \
+        MMA(0, 4, 5); SB();                                                                                                                                                                     \
+        MMA(0, 5, 5); SB();                                                                                                                                                                     \
+        MMA(0, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
+        MMA(0, 6, 1); SB();                                                                                                                                                                     \
+        MMA(0, 6, 2); SB();                                                                                                                                                                     \
+        MMA(0, 6, 3); SB();                                                                                                                                                                     \
+        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
+        MMA(0, 6, 5); SB();                                                                                                                                                                     \
+        MMA(0, 0, 6); SB();                                                                                                                                                                     \
+        MMA(0, 1, 6); SB();                                                                                                                                                                     \
+        MMA(0, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
+        MMA(0, 3, 6); SB();                                                                                                                                                                     \
+        MMA(0, 4, 6); SB();                                                                                                                                                                     \
+        MMA(0, 5, 6); SB();                                                                                                                                                                     \
+        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
+        MMA(0, 7, 0); SB();                                                                                                                                                                     \
+        MMA(0, 7, 1); SB();                                                                                                                                                                     \
+        MMA(0, 7, 2); SB();                                                                                                                                                                     \
+        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
+        MMA(0, 7, 4); SB();                                                                                                                                                                     \
+        MMA(0, 7, 5); SB();                                                                                                                                                                     \
+        MMA(0, 7, 6); SB();                                                                                                                                                                     \
+        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
+        MMA(0, 1, 7); SB();                                                                                                                                                                     \
+        MMA(0, 2, 7); SB();                                                                                                                                                                     \
+        MMA(0, 3, 7); SB();                                                                                                                                                                     \
+        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
+        MMA(0, 5, 7); SB();                                                                                                                                                                     \
+        MMA(0, 6, 7); SB();                                                                                                                                                                     \
+        MMA(0, 7, 7); SB();                                                                                                                                                                     \
+        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
+        MMA(1, 1, 0); SB();                                                                                                                                                                     \
+        MMA(1, 0, 1); SB();                                                                                                                                                                     \
+        MMA(1, 1, 1); SB();                                                                                                                                                                     \
+        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
+        MMA(1, 2, 1); SB();                                                                                                                                                                     \
+        MMA(1, 0, 2); SB();                                                                                                                                                                     \
+        MMA(1, 1, 2); SB();                                                                                                                                                                     \
+        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
+        MMA(1, 3, 0); SB();                                                                                                                                                                     \
+        MMA(1, 3, 1); SB();                                                                                                                                                                     \
+        MMA(1, 3, 2); SB();                                                                                                                                                                     \
+        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
+        MMA(1, 1, 3); SB();                                                                                                                                                                     \
+        MMA(1, 2, 3); SB();                                                                                                                                                                     \
+        MMA(1, 3, 3); SB();                                                                                                                                                                     \
+        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
+        MMA(1, 4, 1); SB();                                                                                                                                                                     \
+        MMA(1, 4, 2); SB();                                                                                                                                                                     \
+        MMA(1, 4, 3); SB();                                                                                                                                                                     \
+        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
+        MMA(1, 1, 4); SB();                                                                                                                                                                     \
+        MMA(1, 2, 4); SB();                                                                                                                                                                     \
+        MMA(1, 3, 4); SB();                                                                                                                                                                     \
+        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
+        MMA(1, 5, 0); SB();                                                                                                                                                                     \
+        MMA(1, 5, 1); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
+        MMA(1, 5, 2); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
+        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
+        MMA(1, 5, 4); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
+        MMA(1, 0, 5); SB();                                                                                                                                                                     \
+        MMA(1, 1, 5); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
+        MMA(1, 2, 5); SB();                                                                                                                                                                     \
+        MMA(1, 3, 5); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
+        MMA(1, 4, 5); SB();                                                                                                                                                                     \
+        MMA(1, 5, 5); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
+        MMA(1, 6, 0); SB();                                                                                                                                                                     \
+        MMA(1, 6, 1); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
+        MMA(1, 6, 2); SB();                                                                                                                                                                     \
+        MMA(1, 6, 3); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
+        MMA(1, 6, 4); SB();                                                                                                                                                                     \
+        MMA(1, 6, 5); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
+        MMA(1, 0, 6); SB();                                                                                                                                                                     \
+        MMA(1, 1, 6); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
+        MMA(1, 2, 6); SB();                                                                                                                                                                     \
+        MMA(1, 3, 6); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
+        MMA(1, 4, 6); SB();                                                                                                                                                                     \
+        MMA(1, 5, 6); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
+        MMA(1, 6, 6); SB();                                                                                                                                                                     \
+        MMA(1, 7, 0); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
+        MMA(1, 7, 1); SB();                                                                                                                                                                     \
+        MMA(1, 7, 2); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
+        MMA(1, 7, 3); SB();                                                                                                                                                                     \
+        MMA(1, 7, 4); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
+        MMA(1, 7, 5); SB();                                                                                                                                                                     \
+        MMA(1, 7, 6); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+        MMA(1, 0, 7); SB();                                                                                                                                                                     \
+        MMA(1, 1, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+        MMA(1, 2, 7); SB();                                                                                                                                                                     \
+        MMA(1, 3, 7); SB();                                                                                                                                                                     \
+        MMA(1, 4, 7); SB();                                                                                                                                                                     \
+        MMA(1, 5, 7); SB();                                                                                                                                                                     \
+        MMA(1, 6, 7); SB();                                                                                                                                                                     \
+        MMA(1, 7, 7); SB();                                                                                                                                                                     \
+    } while (0)
+#define KTILE_T2(BUF, TV, DMA, NEXT)                                                                                                                                                            \
+    do {                                                                                                                                                                                        \
+        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 1, 0); SB();                                                                                                                                                                     \
+        MMA(0, 0, 1); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
+        MMA(0, 1, 1); SB();                                                                                                                                                                     \
+        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 2, 1); SB();                                                                                                                                                                     \
+        MMA(0, 0, 2); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
+        MMA(0, 1, 2); SB();                                                                                                                                                                     \
+        MMA(0, 2, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 3, 0); SB();                                                                                                                                                                     \
+        MMA(0, 3, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
+        MMA(0, 3, 2); SB();                                                                                                                                                                     \
+        MMA(0, 0, 3); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 1, 3); SB();                                                                                                                                                                     \
+        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
+        MMA(0, 3, 3); SB();                                                                                                                                                                     \
+        MMA(0, 4, 0); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                          \
+        MMA(0, 4, 1); SB();                                                                                                                                                                     \
+        MMA(0, 4, 2); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                          \
+        MMA(0, 4, 3); SB();                                                                                                                                                                     \
+        MMA(0, 0, 4); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                          \
+        MMA(0, 1, 4); SB();                                                                                                                                                                     \
+        MMA(0, 2, 4); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                          \
+        MMA(0, 3, 4); SB();                                                                                                                                                                     \
+        MMA(0, 4, 4); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                          \
+        MMA(0, 5, 0); SB();                                                                                                                                                                     \
+        MMA(0, 5, 1); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                          \
+        MMA(0, 5, 2); SB();                                                                                                                                                                     \
+        MMA(0, 5, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                          \
+        MMA(0, 5, 4); SB();                                                                                                                                                                     \
+        MMA(0, 0, 5); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                          \
+        MMA(0, 1, 5); SB();                                                                                                                                                                     \
+        MMA(0, 2, 5); SB();                                                                                                                                                                     \
+        MMA(0, 3, 5); SB();                                                                                                                                                                     \
+        MMA(0, 4, 5); SB();                                                                                                                                                                     \
+        MMA(0, 5, 5); SB();                                                                                                                                                                     \
+        MMA(0, 6, 0); SB();                                                                                                                                                                     \
+        MMA(0, 6, 1); SB();                                                                                                                                                                     \
+        MMA(0, 6, 2); SB();                                                                                                                                                                     \
+        MMA(0, 6, 3); SB();                                                                                                                                                                     \
+        MMA(0, 6, 4); SB();                                                                                                                                                                     \
+        MMA(0, 6, 5); SB();                                                                                                                                                                     \
+        MMA(0, 0, 6); SB();                                                                                                                                                                     \
+        MMA(0, 1, 6); SB();                                                                                                                                                                     \
+        MMA(0, 2, 6); SB();                                                                                                                                                                     \
+        MMA(0, 3, 6); SB();                                                                                                                                                                     \
+        MMA(0, 4, 6); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
+        MMA(0, 5, 6); SB();                                                                                                                                                                     \
+        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
+        MMA(0, 7, 0); SB();                                                                                                                                                                     \
+        MMA(0, 7, 1); SB();                                                                                                                                                                     \
+        MMA(0, 7, 2); SB();                                                                                                                                                                     \
+        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
+        MMA(0, 7, 4); SB();                                                                                                                                                                     \
+        MMA(0, 7, 5); SB();                                                                                                                                                                     \
+        MMA(0, 7, 6); SB();                                                                                                                                                                     \
+        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
+        MMA(0, 1, 7); SB();                                                                                                                                                                     \
+        MMA(0, 2, 7); SB();                                                                                                                                                                     \
+        MMA(0, 3, 7); SB();                                                                                                                                                                     \
+        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
+        MMA(0, 5, 7); SB();                                                                                                                                                                     \
+        MMA(0, 6, 7); SB();                                                                                                                                                                     \
+        MMA(0, 7, 7); SB();                                                                                                                                                                     \
+        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
+        MMA(1, 1, 0); SB();                                                                                                                                                                     \
+        MMA(1, 0, 1); SB();                                                                                                                                                                     \
+        MMA(1, 1, 1); SB();                                                                                                                                                                     \
+        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
+        MMA(1, 2, 1); SB();                                                                                                                                                                     \
+        MMA(1, 0, 2); SB();                                                                                                                                                                     \
+        MMA(1, 1, 2); SB();                                                                                                                                                                     \
+        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
+        MMA(1, 3, 0); SB();                                                                                                                                                                     \
+        MMA(1, 3, 1); SB();                                                                                                                                                                     \
+        MMA(1, 3, 2); SB();                                                                                                                                                                     \
+        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
+        MMA(1, 1, 3); SB();                                                                                                                                                                     \
+        MMA(1, 2, 3); SB();                                                                                                                                                                     \
+        MMA(1, 3, 3); SB();                                                                                                                                                                     \
+        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
+        MMA(1, 4, 1); SB();                                                                                                                                                                     \
+        MMA(1, 4, 2); SB();                                                                                                                                                                     \
+        MMA(1, 4, 3); SB();                                                                                                                                                                     \
+        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
+        MMA(1, 1, 4); SB();                                                                                                                                                                     \
+        MMA(1, 2, 4); SB();                                                                                                                                                                     \
+        MMA(1, 3, 4); SB();                                                                                                                                                                     \
+        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
+        MMA(1, 5, 0); SB();                                                                                                                                                                     \
+        MMA(1, 5, 1); SB();                                                                                                                                                                     \
+        MMA(1, 5, 2); SB();                                                                                                                                                                     \
+        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
+        MMA(1, 5, 4); SB();                                                                                                                                                                     \
+        MMA(1, 0, 5); SB();                                                                                                                                                                     \
+        MMA(1, 1, 5); SB();                                                                                                                                                                     \
+        MMA(1, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
+        MMA(1, 3, 5); SB();                                                                                                                                                                     \
+        MMA(1, 4, 5); SB();                                                                                                                                                                     \
+        MMA(1, 5, 5); SB();                                                                                                                                                                     \
+        MMA(1, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
+        MMA(1, 6, 1); SB();                                                                                                                                                                     \
+        MMA(1, 6, 2); SB();                                                                                                                                                                     \
+        MMA(1, 6, 3); SB();                                                                                                                                                                     \
+        MMA(1, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
+        MMA(1, 6, 5); SB();                                                                                                                                                                     \
+        MMA(1, 0, 6); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
+        MMA(1, 1, 6); SB();                                                                                                                                                                     \
+        MMA(1, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                               \
+        MMA(1, 3, 6); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
+        MMA(1, 4, 6); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
+        MMA(1, 5, 6); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
+        MMA(1, 6, 6); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
+        MMA(1, 7, 0); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
+        MMA(1, 7, 1); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
+        MMA(1, 7, 2); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
+        MMA(1, 7, 3); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
+        MMA(1, 7, 4); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
+        MMA(1, 7, 5); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
+        MMA(1, 7, 6); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
+        MMA(1, 0, 7); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
+        MMA(1, 1, 7); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
+        MMA(1, 2, 7); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+        MMA(1, 3, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+        MMA(1, 4, 7); SB();                                                                                                                                                                     \
+        MMA(1, 5, 7); SB();                                                                                                                                                                     \
+        MMA(1, 6, 7); SB();                                                                                                                                                                     \
+        MMA(1, 7, 7); SB();                                                                                                                                                                     \
+    } while (0)
+#define KTILE_T3(BUF, TV, DMA, NEXT)                                                                                         \
+    do {                                                                                                                     \
+        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                       \
+        MMA(0, 1, 0); SB();                                                                                                  \
+        MMA(0, 0, 1); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                       \
+        MMA(0, 1, 1); SB();                                                                                                  \
+        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                       \
+        MMA(0, 2, 1); SB();                                                                                                  \
+        MMA(0, 0, 2); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                       \
+        MMA(0, 1, 2); SB();                                                                                                  \
+        MMA(0, 2, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                       \
+        MMA(0, 3, 0); SB();                                                                                                  \
+        MMA(0, 3, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                       \
+        MMA(0, 3, 2); SB();                                                                                                  \
+        MMA(0, 0, 3); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                       \
+        MMA(0, 1, 3); SB();                                                                                                  \
+        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                       \
+        MMA(0, 3, 3); SB();                                                                                                  \
+        MMA(0, 4, 0); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                       \
+        MMA(0, 4, 1); SB();                                                                                                  \
+        MMA(0, 4, 2); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                       \
+        MMA(0, 4, 3); SB();                                                                                                  \
+        MMA(0, 0, 4); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                       \
+        MMA(0, 1, 4); SB();                                                                                                  \
+        MMA(0, 2, 4); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                       \
+        MMA(0, 3, 4); SB();                                                                                                  \
+        MMA(0, 4, 4); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                       \
+        MMA(0, 5, 0); SB();                                                                                                  \
+        MMA(0, 5, 1); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                       \
+        MMA(0, 5, 2); SB();                                                                                                  \
+        MMA(0, 5, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                       \
+        MMA(0, 5, 4); SB();                                                                                                  \
+        MMA(0, 0, 5); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                       \
+        MMA(0, 1, 5); SB();                                                                                                  \
+        MMA(0, 2, 5); SB();                                                                                                  \
+        MMA(0, 3, 5); SB();                                                                                                  \
+        MMA(0, 4, 5); SB();                                                                                                  \
+        MMA(0, 5, 5); SB();                                                                                                  \
+        MMA(0, 6, 0); SB();                                                                                                  \
+        MMA(0, 6, 1); SB();                                                                                                  \
+        MMA(0, 6, 2); SB(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();  \
+        MMA(0, 6, 3); SB();                                                                                                  \
+        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                            \
+        MMA(0, 6, 5); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
+        MMA(0, 0, 6); SB();                                                                                                  \
+        MMA(0, 1, 6); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
+        MMA(0, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                            \
+        MMA(0, 3, 6); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
+        MMA(0, 4, 6); SB();                                                                                                  \
+        MMA(0, 5, 6); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
+        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                            \
+        MMA(0, 7, 0); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
+        MMA(0, 7, 1); SB();                                                                                                  \
+        MMA(0, 7, 2); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
+        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                            \
+        MMA(0, 7, 4); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
+        MMA(0, 7, 5); SB();                                                                                                  \
+        MMA(0, 7, 6); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
+        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                            \
+        MMA(0, 1, 7); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                   \
+        MMA(0, 2, 7); SB();                                                                                                  \
+        MMA(0, 3, 7); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                   \
+        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                            \
+        MMA(0, 5, 7); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                   \
+        MMA(0, 6, 7); SB();                                                                                                  \
+        MMA(0, 7, 7); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                   \
+        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                            \
+        MMA(1, 1, 0); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                   \
+        MMA(1, 0, 1); SB();                                                                                                  \
+        MMA(1, 1, 1); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                   \
+        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                            \
+        MMA(1, 2, 1); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                   \
+        MMA(1, 0, 2); SB();                                                                                                  \
+        MMA(1, 1, 2); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                   \
+        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                            \
+        MMA(1, 3, 0); SB();                                                                                                  \
+        MMA(1, 3, 1); SB();                                                                                                  \
+        MMA(1, 3, 2); SB();                                                                                                  \
+        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                            \
+        MMA(1, 1, 3); SB();                                                                                                  \
+        MMA(1, 2, 3); SB();                                                                                                  \
+        MMA(1, 3, 3); SB();                                                                                                  \
+        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                           \
+        MMA(1, 4, 1); SB();                                                                                                  \
+        MMA(1, 4, 2); SB();                                                                                                  \
+        MMA(1, 4, 3); SB();                                                                                                  \
+        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                           \
+        MMA(1, 1, 4); SB();                                                                                                  \
+        MMA(1, 2, 4); SB();                                                                                                  \
+        MMA(1, 3, 4); SB();                                                                                                  \
+        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                           \
+        MMA(1, 5, 0); SB();                                                                                                  \
+        MMA(1, 5, 1); SB();                                                                                                  \
+        MMA(1, 5, 2); SB();                                                                                                  \
+        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                           \
+        MMA(1, 5, 4); SB();                                                                                                  \
+        MMA(1, 0, 5); SB();                                                                                                  \
+        MMA(1, 1, 5); SB();                                                                                                  \
+        MMA(1, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                           \
+        MMA(1, 3, 5); SB();                                                                                                  \
+        MMA(1, 4, 5); SB();                                                                                                  \
+        MMA(1, 5, 5); SB();                                                                                                  \
+        MMA(1, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                           \
+        MMA(1, 6, 1); SB();                                                                                                  \
+        MMA(1, 6, 2); SB();                                                                                                  \
+        MMA(1, 6, 3); SB();                                                                                                  \
+        MMA(1, 6, 4); SB();                                                                                                  \
+        MMA(1, 6, 5); SB();                                                                                                  \
+        MMA(1, 0, 6); SB();                                                                                                  \
+        MMA(1, 1, 6); SB();                                                                                                  \
+        MMA(1, 2, 6); SB();                                                                                                  \
+        MMA(1, 3, 6); SB();                                                                                                  \
+        MMA(1, 4, 6); SB();                                                                                                  \
+        MMA(1, 5, 6); SB();                                                                                                  \
+        MMA(1, 6, 6); SB();                                                                                                  \
+        MMA(1, 7, 0); SB();                                                                                                  \
+        MMA(1, 7, 1); SB();                                                                                                  \
+        MMA(1, 7, 2); SB();                                                                                                  \
+        MMA(1, 7, 3); SB();                                                                                                  \
+        MMA(1, 7, 4); SB();                                                                                                  \
+        MMA(1, 7, 5); SB();                                                                                                  \
+        MMA(1, 7, 6); SB();                                                                                                  \
+        MMA(1, 0, 7); SB();                                                                                                  \
+        MMA(1, 1, 7); SB();                                                                                                  \
+        MMA(1, 2, 7); SB();                                                                                                  \
+        MMA(1, 3, 7); SB();                                                                                                  \
+        MMA(1, 4, 7); SB();                                                                                                  \
+        MMA(1, 5, 7); SB();                                                                                                  \
+        MMA(1, 6, 7); SB();                                                                                                  \
+        MMA(1, 7, 7); SB();                                                                                                  \
+    } while (0)
+// ---- end of generated schedule ----
+#define KLOOP(KT)                                   \
+    do {                                            \
+        int t = 0;                                  \
+        for (; t + 2 < nk; t += 2) {                \
+            KT(0, t, true, true);                   \
+            KT(1, t + 1, true, true);               \
+        }                                           \
+        KT(0, t, false, true);                      \
+        KT(1, t + 1, false, false);                 \
+    } while (0)
+        if constexpr (SCH == 0) KLOOP(KTILE_T0);
+        else if constexpr (SCH == 1) KLOOP(KTILE_T1);
+        else if constexpr (SCH == 2) KLOOP(KTILE_T2);
+        else KLOOP(KTILE_T3);
+#undef KLOOP
+#undef KTILE_T1
+#undef KTILE_T2
+#undef KTILE_T3
+#undef KTILE_T0
+#undef MMA
+
+        // ---- epilogue: both buffers are dead (every fragment read retired before barrier #1 of the last K-tile, no DMA in flight) ----
+        TMARK(2);
+        float part = 0.f;
+        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (g.cdt == OTTER_F32 || g.wide);
+        if (full) {
+            float* blk4 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
+            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+            else part = tail_wave_full<EPI, false>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+        } else {
+            float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                park_stripe(blk, acc, st, lane);
+                __builtin_amdgcn_wave_barrier();
+                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 128 + (st >> 1) * 32, n0 + wn * 128 + (st & 1) * 64, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        TMARK(3);
+        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+        __syncthreads();  // the next tile's prologue DMA overwrites the stripes
+        TMARK(4);
+        ++tcount;
+    }
+#undef LDF
+#undef SB
+#undef TMARK
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // bf16 small-grid kernel (variant 25): 128x128 tile, 4 waves of 64x64, BK = 64 stages in a 4-deep LDS-DMA ring.
 // Why: the gated block's and the perceiver's projections with N or M = 512 are at most 128-256 tiles -- one block per CU at
 // best -- with a LONG reduction (K = 4096): the register-staged double buffer of gemm_bf16_kernel<128,128> pays one global
@@ -2553,7 +3244,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 int g_variant = 0;
 int g_debug = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_S4 = 25, CFG_F32 = 100 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_S4 = 25, CFG_T4 = 26, CFG_T4B = 27, CFG_T4C = 28, CFG_T4M = 29, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
@@ -2563,15 +3254,15 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
         // interleaved A/B medians on MI355X (tools/gemm_ab.py): round 2's one-wave-per-SIMD kernel with the
         // register-resident K-tile (variant 18) beats round 1's balanced 8-wave phased schedule (variant 13) on all three
         // FFN shapes (1.29 / 1.49 / 1.43 PF vs 1.19 / 1.39 / 1.37 on one box); it needs K % 128 == 0, else 13 stays
-        if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = (K % 128 == 0 && !wide) ? CFG_R4 : CFG_PHLB;
-        else if (K % 256 == 0 && K >= 1024 && !wide && cdiv64(M, 128) * cdiv64(N, 128) <= 512) v = CFG_S4;   // few tiles, long reduction: the ring
+        if (cdiv64(M, 256) * cdiv64(N, 256) >= 192) v = (K % 128 == 0 && !wide) ? CFG_T4 : CFG_PHLB;
+        else if (K % 256 == 0 && K >= 512 && !wide && cdiv64(M, 128) * cdiv64(N, 128) <= 512) v = CFG_S4;   // few tiles, long reduction: the ring
         else v = CFG_128;
     }
     if ((v == CFG_MS4 || v == CFG_MS5 || v == CFG_MS5B) && (K % 32 != 0)) v = CFG_256_GLDS;
     if (v == CFG_WS && K % 64 != 0) v = CFG_256;
     const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB || v == CFG_PH2B || v == CFG_PHDB;
     if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
-    if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C || v == CFG_R4P || v == CFG_R4M || v == CFG_R4N) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
+    if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C || v == CFG_R4P || v == CFG_R4M || v == CFG_R4N || v == CFG_T4 || v == CFG_T4B || v == CFG_T4C || v == CFG_T4M) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
     if (v == CFG_S4 && (K % 256 != 0 || wide)) v = CFG_128;
     if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
@@ -2685,6 +3376,22 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
 #undef LAUNCH_R4
         return OTTER_OK;
     }
+    if (cfg == CFG_T4 || cfg == CFG_T4B || cfg == CFG_T4C || cfg == CFG_T4M) {
+        const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;
+        unsigned pg = grid.x < 256u ? grid.x : 256u;
+#define LAUNCH_T4(SCH_)                                                                                                    \
+    do {                                                                                                                   \
+        static bool once = false;                                                                                          \
+        if (!once) { int rc = set_smem(gemm_bf16_t4_kernel<EPI, SCH_>, smem); if (rc) return rc; once = true; }            \
+        hipLaunchKernelGGL((gemm_bf16_t4_kernel<EPI, SCH_>), dim3(pg), dim3(256), smem, st, g);                            \
+    } while (0)
+        if (cfg == CFG_T4) LAUNCH_T4(0);
+        else if (cfg == CFG_T4B) LAUNCH_T4(1);
+        else if (cfg == CFG_T4C) LAUNCH_T4(2);
+        else LAUNCH_T4(3);
+#undef LAUNCH_T4
+        return OTTER_OK;
+    }
     if (cfg == CFG_S4) {
         static bool once = false;
         const int smem = 4 * 32768;  // the ring; the tail's parking buffers (4 waves x 2 stripes = 69632 B) alias it
@@ -2731,7 +3438,7 @@ int otter_device_check(void) {
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 25) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 29) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     g_variant = variant;
     return OTTER_OK;
 }

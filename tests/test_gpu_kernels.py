@@ -186,7 +186,7 @@ def test_llama_ops_golden(ops):
 GEMM_SHAPES = [(48, 128, 48), (200, 136, 328), (257, 512, 64), (64, 384, 1024), (520, 264, 200), (300, 520, 256), (513, 260, 128)]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26])
 @pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
 def test_gemm_bf16_store(ops, variant, M, N, Kd):
     ops.set_gemm_variant(variant)
@@ -214,7 +214,7 @@ def test_gemm_f32_store(ops, M, N, Kd):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25])
+@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26])
 def test_gemm_epilogues(ops, dt, variant):
     from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
 
@@ -262,7 +262,7 @@ def test_gemm_epilogues(ops, dt, variant):
         ops.set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("variant", [17, 18, 19, 20, 21, 22, 23, 25])
+@pytest.mark.parametrize("variant", [17, 18, 19, 20, 21, 22, 23, 25, 26])
 @pytest.mark.parametrize("out_dt", ["bf16", "f32"])
 def test_gemm_full_tile_fast_tail(ops, variant, out_dt):
     """The one-wave-per-SIMD kernels take an unrolled, double-buffered tail on full in-bounds tiles: every epilogue kind and
@@ -344,7 +344,7 @@ def test_gemm_big_variants_agree(ops):
     B = to_dev(r.standard_normal((N, Kd)), torch.bfloat16)
     ref = host(A).astype(np.float64) @ host(B).astype(np.float64).T
     outs = []
-    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25):
+    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26):
         ops.set_gemm_variant(v)
         outs.append(ops.gemm_nt(A, B, out_dtype=torch.float32))
     ops.set_gemm_variant(0)

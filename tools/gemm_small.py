@@ -1,5 +1,5 @@
 """Small-grid GEMM shapes of the gated cross-attention block / perceiver (N or M = 512): default config choice vs the 128x128 register-staged
-kernel (variant 1), the 128x128 LDS-DMA ring (variant 25) and hipBLASLt.  Usage: gemm_small.py"""
+kernel (variant 1), the 128x128 LDS-DMA ring (variant 25) and hipBLASLt.  Usage: gemm_small.py [MxNxK ...]"""
 import json, os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,8 @@ def bench(fn, iters=20):
     return s.elapsed_time(e) / iters * 1e3
 
 
-for (M, N, K) in [(4096, 512, 4096), (512, 4096, 4096), (4096, 4096, 512), (512, 4096, 1024), (512, 1024, 4096), (2560, 1024, 1024)]:
+SHAPES = [tuple(int(x) for x in a.split('x')) for a in sys.argv[1:]]
+for (M, N, K) in SHAPES or [(4096, 512, 4096), (512, 4096, 4096), (4096, 4096, 512), (512, 4096, 1024), (512, 1024, 4096), (2560, 1024, 1024)]:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)

@@ -1,0 +1,74 @@
+"""Generates the 128-slot K-tile schedule macro of gemm_bf16_t4_kernel (csrc/gemm.hip, variant 26): variant 18's pipeline
+(two 64 KB buffers, register-resident K-tile, DMA of K-tile t+2 into the buffer just freed) issued as v_mfma_f32_16x16x32_bf16.
+`python tools/gen/gemm_t4_schedule.py` prints it; paste between the GENERATED markers.
+
+One K-tile (BK = 64) of a 128x128 wave tile = 2 k-steps x 64 MFMAs (16x16x32, 16 cycles each).  Slot j = MFMA j + at most one filler.
+  T0: reads of k-step 1 on even slots 0..30 (k-step 0 was read by the previous iteration), lgkmcnt(0) + barrier #1 after slot 38 (the
+      buffer is free), the 16 DMA pieces of K-tile t+2 on slots 40, 44, .. 100, vmcnt(pieces so far) + barrier #2 after slot 94
+      (K-tile t+1 readable), its k-step-0 reads on odd slots 97..127 -- the same cadence in cycles as KTILE_S0 of variant 18
+      (one LDS read per 32 cycles and wave = the LDS pipe's rate with four waves reading, one DMA piece per 64).
+MFMA order inside a k-step: shells of the 8x8 block grid (block (mi, ni) belongs to shell max(mi, ni)), so that fragment s of
+either operand is first needed at slot s*s and the read order m0 n0 m1 n1 .. delivers them in the order of first use."""
+
+
+def shell_order():
+    o = []
+    for s in range(8):
+        o += [(s, j) for j in range(s)]          # row s against the columns already open
+        o += [(i, s) for i in range(s + 1)]      # column s
+    assert len(o) == 64 and len(set(o)) == 64
+    return o
+
+
+ORD = shell_order()
+FR = [(t, i) for i in range(8) for t in ("m", "n")]   # request order of a k-step's 16 fragments
+
+
+def rd(ks, r, buf):
+    t, i = FR[r]
+    return "LDF(f%s[%d][%d], %s, %s, %s, %d, %d);" % (t, ks, i, "rb" if t == "n" else "ra", "rb_hi" if t == "n" else "ra_hi", buf, ks, i)
+
+
+def schedule(name, reads, b1, dma, b2, xreads, merged=False):
+    """merged: ONE barrier per K-tile -- at b1 the wave also waits for its DMA pieces of K-tile t+1 (all issued during the previous
+    iteration, nothing newer in flight: vmcnt(0)); the same barrier frees the current buffer and publishes K-tile t+1; b2 is None."""
+    lines, issued = [], 0
+    for j in range(128):
+        ks, q = j >> 6, j & 63
+        mi, ni = ORD[q]
+        parts = ["MMA(%d, %d, %d); SB();" % (ks, mi, ni)]
+        for r in reads.get(j, []):
+            parts.append(rd(1, r, "BUF") + " SB();")
+        if j == b1 and merged:
+            parts.append('asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
+        elif j == b1:
+            parts.append('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
+        for p in dma.get(j, []):
+            parts.append("if (DMA) dma(BUF, (TV) + 2, %d); SB();" % p)
+            issued += 1
+        if b2 is not None and j == b2:
+            parts.append('if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(%d)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); '
+                         "__builtin_amdgcn_s_barrier(); } SB();" % issued)
+        for r in xreads.get(j, []):
+            parts.append("if (NEXT) { " + rd(0, r, "(BUF) ^ 1") + " } SB();")
+        lines.append("        " + " ".join(parts))
+    assert issued == 16
+    w = max(len(x) for x in lines) + 2
+    head = "#define %s(BUF, TV, DMA, NEXT)" % name
+    out = [head + " " * (w - len(head)) + "\\", "    do {" + " " * (w - 8) + "\\"]
+    out += [x + " " * (w - len(x)) + "\\" for x in lines]
+    out.append("    } while (0)")
+    return "\n".join(out)
+
+
+T0 = schedule("KTILE_T0", {2 * r: [r] for r in range(16)}, 38, {40 + 4 * p: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)})
+# T1: k-step-1 reads on EVERY slot 0..15, everything 8 slots earlier
+T1 = schedule("KTILE_T1", {r: [r] for r in range(16)}, 30, {32 + 4 * p: [p] for p in range(16)}, 90, {91 + 2 * r: [r] for r in range(16)})
+# T2: barrier #1 8 slots later (reads get 16 slots to land), X' reads on every slot 108..123
+T2 = schedule("KTILE_T2", {2 * r: [r] for r in range(16)}, 46, {48 + 4 * p: [p] for p in range(16)}, 106, {108 + r: [r] for r in range(16)})
+# T3: one barrier per K-tile (as KTILE_S3 of variant 22), X' reads on odd slots right after it
+T3 = schedule("KTILE_T3", {2 * r: [r] for r in range(16)}, 38, {40 + 4 * p: [p] for p in range(16)}, None, {41 + 2 * r: [r] for r in range(16)}, merged=True)
+print(T0)
+print(T1)
+print(T2)
+print(T3)
