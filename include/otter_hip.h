@@ -245,6 +245,11 @@ int otter_rope_strided(const void* x, void* y, const float* cos_t, const float* 
  * f32, n elements (multiple of 8), in place allowed. */
 int otter_quick_gelu(const void* x, void* y, int64_t n, int dtype, void* stream);
 
+/* Exact-erf GELU of the frozen MPT decoder's MLP (/root/reference/src/otter_ai/models/mpt/blocks.py:37-49: act = nn.GELU(approximate=
+ * 'none')) and its backward dx = dy * (Phi(x) + x phi(x)); bf16 or f32, n elements (multiple of 8), y == x / dx == dy allowed. */
+int otter_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int otter_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, void* stream);
+
 /* SwiGLU of the LLaMA MLP (/root/reference/xformers_model/llama.py:216-223: down(act(gate(x)) * up(x)), act = SiLU) on the
  * [rows, 2*I] bf16 output of the concatenated gate|up projection: h[rows, I] = silu(g) * u;  backward writes
  * dgate_up[rows, 2*I] = (dh * u * silu'(g) | dh * silu(g)). */

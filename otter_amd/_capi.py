@@ -91,6 +91,8 @@ SIGNATURES = {
     "otter_rope": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _int, _int, _vp]),
     "otter_rope_strided": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _int, _i64, _i64, _vp]),
     "otter_quick_gelu": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "otter_gelu_fwd": (_int, [_vp, _vp, _i64, _int, _vp]),
+    "otter_gelu_bwd": (_int, [_vp, _vp, _vp, _i64, _int, _vp]),
     "otter_swiglu_fwd": (_int, [_vp, _vp, _i64, _i64, _vp]),
     "otter_swiglu_bwd": (_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "otter_add_frame_embs": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _i64, _vp]),

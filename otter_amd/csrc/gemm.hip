@@ -44,6 +44,7 @@ struct GemmArgs {
     float* partial;
     int gm, gn;
     int dbg;  // diagnostics only (otter_gemm_set_debug): bit0 = skip K-loop global loads, bit1 = skip MFMAs
+    int order;  // tile order override (diagnostics, see tile_of_block)
     int wide;  // bf16 output and every tensor the fused tail touches allows 8-element accesses (N, ldc, ldc2, ldr, ldaux % 8 == 0)
 };
 
@@ -528,12 +529,21 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs& g, int bid, int& t
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    if ((g.gm & 7) == 0 && (g.gn & 3) == 0) {
+    // super-tile shape: 2^lm (M) x 2^(5-lm) (N) tiles, default 8 x 4; g.order (otter_gemm_set_debug bits 9-12, diagnostics) overrides
+    // it: bits 0-2 = lm + 1 (0 = default), bit 3 = walk the super-tiles N-major instead of M-major
+    const int lm = (g.order & 7) ? (g.order & 7) - 1 : 3;
+    const int smt = 1 << lm, snt = 32 >> lm;
+    if ((g.gm & (smt - 1)) == 0 && (g.gn & (snt - 1)) == 0) {
         // super-tiles of 8 (M) x 4 (N) tiles: the ~32 blocks an XCD has resident at any time form a compact patch, so its
         // L2 holds 8 A-slabs + 4 B-slabs per K-step (384 KB) instead of 16 + 2 (576 KB) for the plain M-sweep
-        const int st = swz >> 5, w = swz & 31, gms = g.gm >> 3;
-        tile_m = (st % gms) * 8 + (w & 7);
-        tile_n = (st / gms) * 4 + (w >> 3);
+        const int st = swz >> 5, w = swz & 31, gms = g.gm >> lm, gns = g.gn / snt;
+        if (g.order & 8) {
+            tile_n = (st % gns) * snt + (w >> lm);
+            tile_m = (st / gns) * smt + (w & (smt - 1));
+        } else {
+            tile_m = (st % gms) * smt + (w & (smt - 1));
+            tile_n = (st / gms) * snt + (w >> lm);
+        }
     } else {
         tile_m = swz % g.gm;
         tile_n = swz / g.gm;
@@ -3243,6 +3253,7 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int64_
 // ---- configuration choice (shared by the launcher and otter_gemm_num_partials) ----
 int g_variant = 0;
 int g_debug = 0;
+int g_order = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
 enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_S4 = 25, CFG_T4 = 26, CFG_T4B = 27, CFG_T4C = 28, CFG_T4M = 29, CFG_F32 = 100 };
 
@@ -3453,6 +3464,7 @@ int otter_gemm_read_timeline(unsigned long long* out, int n) {
 int otter_gemm_set_debug(int flags) {
     g_debug = flags & 255;  // bit 64: tile-phase timeline of variants 18-20 (otter_gemm_read_timeline)
     g_narrow_epilogue = (flags & 256) ? 1 : 0;
+    g_order = (flags >> 9) & 15;  // tile-order override, see tile_of_block
     return OTTER_OK;
 }
 
@@ -3502,6 +3514,7 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
     int bm, bn;
     cfg_tiles(cfg, bm, bn);
     g.dbg = g_debug;
+    g.order = g_order;
     // (fp32 outputs stay on the 4-wide tail: there a lane's 4 columns are already a 16-byte store and 16 lanes cover a
     //  whole 256-byte row run; the 8-wide form would split every row into interleaved 16-byte halves: measured +15 %)
     g.wide = (c_dtype == OTTER_BF16 && N % 8 == 0 && ldc % 8 == 0 && (!g.C2 || g.ldc2 % 8 == 0) && (g.kind != OTTER_EPI_SCALE_RES || g.ldr % 8 == 0) &&

@@ -250,6 +250,30 @@ def add_rms_norm(x, delta, weight, eps=1e-6, out_dtype=None):
     return AddRMSNormFn.apply(x, delta, weight, eps, out_dtype or x.dtype)
 
 
+class GeluFn(torch.autograd.Function):
+    """Exact-erf GELU of the decoder MLP (mpt/blocks.py:37-49) on csrc/elementwise.hip's one-pass kernels (forward 2 x, backward 3 x the
+    activation bytes at ~6 TB/s; replaces torch's GeluCUDAKernelImpl / GeluBackwardCUDAKernelImpl: 72 + 89 -> 40 + 60 us per layer at C2)."""
+
+    @staticmethod
+    def forward(ctx, u):
+        u = u.contiguous()
+        ctx.save_for_backward(u)
+        return ops.gelu_fwd(u)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (u,) = ctx.saved_tensors
+        dh = dh.contiguous() if dh.dtype == u.dtype else dh.to(u.dtype).contiguous()
+        return ops.gelu_bwd(u, dh)
+
+
+def gelu(u):
+    """nn.GELU() (approximate='none'): HIP kernels for GPU bf16 / f32 tensors with numel % 8 == 0, torch otherwise (CPU parity mode)."""
+    if u.is_cuda and u.dtype in (torch.bfloat16, torch.float32) and u.numel() % 8 == 0 and u.numel() > 0:
+        return GeluFn.apply(u)
+    return torch.nn.functional.gelu(u)
+
+
 class SwiGLUFn(torch.autograd.Function):
     """h = silu(gate) * up on the fused [.., 2*I] gate|up projection output (xformers_model/llama.py:216-223), bf16."""
 

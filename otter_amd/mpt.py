@@ -148,7 +148,10 @@ class MPTMLP(nn.Module):
         self.down_proj = FrozenAwareLinear(expansion_ratio * d_model, d_model, bias=bias)
 
     def forward(self, x):
-        return self.down_proj(self.act(self.up_proj(x)))
+        u = self.up_proj(x)
+        if u.is_cuda and os.environ.get("OTTER_TORCH_GELU") != "1":
+            return self.down_proj(OF.gelu(u))      # csrc/elementwise.hip gelu_fwd / gelu_bwd (same exact-erf form as nn.GELU())
+        return self.down_proj(self.act(u))
 
 
 def ops_decode_attn(q, k, v, slopes, key_valid, scale):

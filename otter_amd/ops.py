@@ -398,6 +398,26 @@ def quick_gelu_(x):
     return x
 
 
+def gelu_fwd(x):
+    """Exact-erf GELU (nn.GELU() default) of a contiguous bf16 / f32 tensor, numel % 8 == 0 (MPT MLP activation)."""
+    K.require_cuda(x)
+    if not x.is_contiguous() or x.numel() % 8:
+        raise K.OtterHipError("gelu_fwd: contiguous tensor with numel % 8 == 0")
+    y = torch.empty_like(x)
+    K.check(K.lib().otter_gelu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), K.dt(x), K.stream()), "gelu_fwd")
+    return y
+
+
+def gelu_bwd(x, dy):
+    """dx = dy * gelu'(x) (exact-erf form), same layout rules as gelu_fwd."""
+    K.require_cuda(x, dy)
+    if not x.is_contiguous() or not dy.is_contiguous() or x.numel() % 8 or dy.shape != x.shape or dy.dtype != x.dtype:
+        raise K.OtterHipError("gelu_bwd: x and dy must be contiguous, same shape / dtype, numel % 8 == 0")
+    dx = torch.empty_like(x)
+    K.check(K.lib().otter_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), K.dt(x), K.stream()), "gelu_bwd")
+    return dx
+
+
 def swiglu_fwd(gu2d):
     """gu2d [rows, 2*I] bf16 contiguous (gate | up) -> h [rows, I] = silu(gate) * up."""
     K.require_cuda(gu2d)

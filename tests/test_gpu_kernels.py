@@ -539,6 +539,33 @@ def test_rope_strided_qkv_buffer(ops):
     assert np.array_equal(host(dg[:, :, 2]), g[:, :, 2])
 
 
+def test_gelu_fwd_bwd(ops):
+    """Decoder-MLP GELU kernels vs the oracle's exact-erf GELU (float64): fp32 to 1e-6 of the range, bf16 to output rounding;
+    in-place forms; the tails (|x| up to 12) must come out as 0 / x exactly like erf's saturation."""
+    from oracle import otter_oracle as O
+
+    r = rng(53)
+    x = np.concatenate([r.standard_normal(4096 - 16) * 3, np.array([0.0, -0.0, 12.0, -12.0, 6.5, -6.5, 1e-4, -1e-4, 40.0, -40.0, 0.5, -0.5, 2.0, -2.0, 8.0, -8.0])])
+    dy = r.standard_normal(4096)
+    ref, gref = O.gelu_fwd(x.astype(np.float64)), O.gelu_grad(x.astype(np.float64))
+    xf, df = to_dev(x, torch.float32), to_dev(dy, torch.float32)
+    assert np.abs(host(ops.gelu_fwd(xf)) - ref).max() < 2e-6 * 40
+    assert np.abs(host(ops.gelu_bwd(xf, df)) - dy * gref).max() < 5e-6
+    xb, db = bf16_round(x), bf16_round(dy)
+    refb, grefb = O.gelu_fwd(xb.astype(np.float64)), O.gelu_grad(xb.astype(np.float64))
+    assert relmax(host(ops.gelu_fwd(to_dev(xb, torch.bfloat16))), refb) < 5e-3
+    assert relmax(host(ops.gelu_bwd(to_dev(xb, torch.bfloat16), to_dev(db, torch.bfloat16))), db * grefb) < 5e-3
+    # autograd wrapper == torch's GELU on the same bf16 input (values and gradient), 3-D shape
+    from otter_amd import functional as OF
+    u = to_dev(bf16_round(r.standard_normal((2, 24, 64)) * 2), torch.bfloat16).requires_grad_(True)
+    u2 = u.detach().clone().requires_grad_(True)
+    g = to_dev(bf16_round(r.standard_normal((2, 24, 64))), torch.bfloat16)
+    OF.gelu(u).backward(g)
+    torch.nn.functional.gelu(u2).backward(g)
+    assert relmax(host(OF.gelu(u)), host(torch.nn.functional.gelu(u2))) < 8e-3
+    assert relmax(host(u.grad), host(u2.grad)) < 8e-3
+
+
 def test_swiglu_fwd_bwd(ops):
     r = rng(47)
     rows, I = 53, 176
