@@ -230,6 +230,194 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
     out[col] = accumulate ? out[col] + s : s;
 }
 
+// ---- coalesced variants of the two row kernels for the training configuration (fp32 residual stream, bf16 branch tensors, D % 512 == 0) ----
+// The generic kernels above give a lane 8 CONSECUTIVE columns, so an fp32 row is read as two float4 instructions whose lanes are 32 B
+// apart: every 128-B line is requested by both.  Here a lane owns columns [c*512 + 4*lane, +4) and [c*512 + 256 + 4*lane, +4): every
+// fp32 instruction covers 1 KB contiguous, every bf16 instruction 512 B contiguous.  The backward keeps x as loaded (fp32) and dy packed
+// (bf16) and recomputes x-hat and dy*gamma in the second phase (gamma comes from L2): 96 live registers instead of 128 -> <= 128 VGPRs,
+// four waves per SIMD, all 4096 rows of the C2 stream resident at once (the generic backward: 178 VGPRs, two waves per SIMD, two rounds).
+__device__ __forceinline__ void ld4(const void* p, int64_t idx, int dt, float (&v)[4]) {
+    if (dt == OTTER_BF16) {
+        const uint2 r = *reinterpret_cast<const uint2*>((const bf16_t*)p + idx);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    } else {
+        const float4 r = *reinterpret_cast<const float4*>((const float*)p + idx);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+}
+__device__ __forceinline__ void st4bf(bf16_t* p, int64_t idx, const float (&v)[4]) {
+    uint2 r;
+    r.x = pack2bf(v[0], v[1]);
+    r.y = pack2bf(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p + idx) = r;
+}
+__device__ __forceinline__ void st4f(float* p, int64_t idx, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p + idx) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+template <int NCH, bool RMS>
+__global__ __launch_bounds__(256) void norm_fwd_c_kernel(const float* __restrict__ x, const void* __restrict__ gamma, const void* __restrict__ beta,
+                                                         int wdt, bf16_t* __restrict__ y, otter_rowmap ymap, bf16_t* __restrict__ y2,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int D, float eps,
+                                                         const void* __restrict__ delta, int ddt, float* __restrict__ xsum) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nrun = D >> 9;
+    const int64_t base = row * D + lane * 4;
+    float v[NCH][2][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c < nrun) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t o = base + c * 512 + h * 256;
+                ld4(x, o, OTTER_F32, v[c][h]);
+                if (delta) {
+                    float dl[4];
+                    ld4(delta, o, ddt, dl);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[c][h][i] += dl[i];
+                    st4f(xsum, o, v[c][h]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s += RMS ? v[c][h][i] * v[c][h][i] : v[c][h][i];
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[c][h][i] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    float mu = 0.f, var;
+    if (RMS) {
+        var = s / (float)D;
+    } else {
+        mu = s / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (c < nrun) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float d = v[c][h][i] - mu;
+                        q += d * d;
+                    }
+            }
+        var = wave_sum(q) / (float)D;
+    }
+    const float rs = 1.0f / sqrtf(var + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+    const int64_t obase = map_row(row, ymap) * D + lane * 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        if (c < nrun) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int col = c * 512 + h * 256 + lane * 4;
+                float g[4], b[4], o[4];
+                if (gamma) ld4(gamma, col, wdt, g);
+                if (beta) ld4(beta, col, wdt, b);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = (v[c][h][i] - mu) * rs;
+                    if (gamma) t *= g[i];
+                    if (beta) t += b[i];
+                    o[i] = t;
+                }
+                st4bf(y, obase + c * 512 + h * 256, o);
+                if (y2) st4bf(y2, base + c * 512 + h * 256, o);
+            }
+        }
+    }
+}
+
+template <int NCH, bool RMS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4)))
+void norm_bwd_dx_c_kernel(const bf16_t* __restrict__ dy, otter_rowmap dymap, const float* __restrict__ x, const void* __restrict__ gamma, int wdt,
+                          const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dres, float* __restrict__ dx,
+                          bf16_t* __restrict__ dx2, int64_t rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nrun = D >> 9;
+    const float mu = RMS ? 0.f : mean[row];
+    const float rs = rstd[row];
+    const int64_t base = row * D + lane * 4;
+    const int64_t dbase = map_row(row, dymap) * D + lane * 4;
+    float xr[NCH][2][4];
+    uint2 dr[NCH][2];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (c < nrun) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ld4(x, base + c * 512 + h * 256, OTTER_F32, xr[c][h]);
+                dr[c][h] = *reinterpret_cast<const uint2*>(dy + dbase + c * 512 + h * 256);
+            }
+        }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (c < nrun) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float gm[4];
+                if (gamma) ld4(gamma, c * 512 + h * 256 + lane * 4, wdt, gm);
+                const float dv[4] = {__uint_as_float(dr[c][h].x << 16), __uint_as_float(dr[c][h].x & 0xffff0000u),
+                                     __uint_as_float(dr[c][h].y << 16), __uint_as_float(dr[c][h].y & 0xffff0000u)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = (xr[c][h][i] - mu) * rs;
+                    const float gg = gamma ? dv[i] * gm[i] : dv[i];
+                    s1 += gg;
+                    s2 += gg * t;
+                }
+            }
+        }
+    const float m1 = RMS ? 0.f : wave_sum(s1) / (float)D;
+    const float m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+        if (c < nrun) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t o = base + c * 512 + h * 256;
+                float gm[4], r[4], out[4];
+                if (gamma) ld4(gamma, c * 512 + h * 256 + lane * 4, wdt, gm);
+                if (dres) ld4(dres, o, OTTER_F32, r);
+                const float dv[4] = {__uint_as_float(dr[c][h].x << 16), __uint_as_float(dr[c][h].x & 0xffff0000u),
+                                     __uint_as_float(dr[c][h].y << 16), __uint_as_float(dr[c][h].y & 0xffff0000u)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = (xr[c][h][i] - mu) * rs;
+                    const float gg = gamma ? dv[i] * gm[i] : dv[i];
+                    float u = (gg - m1 - t * m2) * rs;
+                    if (dres) u += r[i];
+                    out[i] = u;
+                }
+                st4f(dx, o, out);
+                if (dx2) st4bf(dx2, o, out);
+            }
+        }
+}
+
+// OTTER_NORM_VARIANT (read once): 0 = generic kernels only, 1 (default) = coalesced kernels where they apply
+int norm_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OTTER_NORM_VARIANT"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 int pick_nch(int64_t D) {
     int n = 1;
     while ((int64_t)n * 512 < D) n <<= 1;
@@ -250,6 +438,18 @@ int launch_fwd(const void* x, int xdt, const void* gamma, const void* beta, int 
     OTTER_REQUIRE(D % 8 == 0 && D <= 8192, "norm_fwd: D=%ld must be a multiple of 8 and <= 8192", (long)D);
     const int nch = pick_nch(D);
     dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+    if (norm_variant() == 1 && xdt == OTTER_F32 && ydt == OTTER_BF16 && D % 512 == 0 && nch <= 8) {
+#define LC(N) hipLaunchKernelGGL((norm_fwd_c_kernel<N, RMS>), grid, block, 0, st, (const float*)x, gamma, beta, wdt, (bf16_t*)y, ymap, (bf16_t*)y2, mean, rstd, rows, (int)D, eps, delta, ddt, (float*)xsum)
+        switch (nch) {
+            case 1: LC(1); break;
+            case 2: LC(2); break;
+            case 4: LC(4); break;
+            default: LC(8); break;
+        }
+#undef LC
+        OTTER_CHECK_LAUNCH("norm_fwd_c");
+        return OTTER_OK;
+    }
 #define L(N) hipLaunchKernelGGL((norm_fwd_kernel<N, RMS>), grid, block, 0, st, x, xdt, gamma, beta, wdt, y, ydt, ymap, y2, mean, rstd, rows, (int)D, eps, delta, ddt, xsum)
     switch (nch) {
         case 1: L(1); break;
@@ -270,7 +470,18 @@ int launch_bwd(const void* dy, int dydt, otter_rowmap dymap, const void* x, int 
     OTTER_REQUIRE(dy && x && rstd && rows > 0, "norm_bwd: null pointer or empty shape");
     OTTER_REQUIRE(D % 8 == 0 && D <= 8192, "norm_bwd: D=%ld must be a multiple of 8 and <= 8192", (long)D);
     const int nch = pick_nch(D);
-    if (dx) {
+    if (dx && norm_variant() == 1 && xdt == OTTER_F32 && dydt == OTTER_BF16 && dxdt == OTTER_F32 && D % 512 == 0 && nch <= 8) {
+        dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+#define LC(N) hipLaunchKernelGGL((norm_bwd_dx_c_kernel<N, RMS>), grid, block, 0, st, (const bf16_t*)dy, dymap, (const float*)x, gamma, wdt, mean, rstd, (const float*)dres, (float*)dx, dx2, rows, (int)D)
+        switch (nch) {
+            case 1: LC(1); break;
+            case 2: LC(2); break;
+            case 4: LC(4); break;
+            default: LC(8); break;
+        }
+#undef LC
+        OTTER_CHECK_LAUNCH("norm_bwd_dx_c");
+    } else if (dx) {
         dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
 #define L(N) hipLaunchKernelGGL((norm_bwd_dx_kernel<N, RMS>), grid, block, 0, st, dy, dydt, dymap, x, xdt, gamma, wdt, mean, rstd, dres, dx, dxdt, dx2, rows, (int)D)
         switch (nch) {
