@@ -60,8 +60,17 @@ __device__ unsigned long long* g_flash_stamps = nullptr;
         if (g_flash_stamps && blockIdx.x == 3 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && (slot) < 64) \
             g_flash_stamps[slot] = t_;                                                                    \
     } while (0)
+// dK/dV kernel: stamps go to LDS (no vmcnt traffic: the kernel's counted s_waitcnt vmcnt(N) must keep meaning its DMA pieces) and are
+// copied out after the loop; block 0, wave 0
+#define DSTAMP(slot)                                                                                              \
+    do {                                                                                                          \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                 \
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 96) reinterpret_cast<unsigned long long*>(smem + 50688)[slot] = t_; \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define DSTAMP(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ f32x16_t zero16() {
@@ -252,15 +261,42 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
 // the co-resident wave's MFMAs.  Less VALU: tiles entirely below the diagonal skip the mask arithmetic, and the
 // accumulator is only rescaled when some row's running maximum grew by more than 2^8 (stale maxima are exact: P <= 256).
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void flash_dma_tile(__amdgpu_buffer_rsrc_t rk, __amdgpu_buffer_rsrc_t rv, char* kdst, char* vdst,
+// LDS-DMA issued through inline asm.  Why not the builtin: hipcc (ROCm 7.2) treats a builtin LDS-DMA as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read it cannot prove disjoint -- in these kernels every fragment read of the CURRENT tile,
+// issued right after the DMA of the NEXT one.  That drained the prefetch every iteration (dK/dV kernel: 3 900 cycles per 32-row tile
+// against 1 024 of MFMA work, tools/flash_timeline_dkv.py).  An asm statement is invisible to that bookkeeping; completion is counted by
+// hand (the explicit `s_waitcnt vmcnt(N)` + raw `s_barrier` at the top of each iteration, which the kernels already had).  M0 (the LDS
+// destination) is saved and restored inside the statement; the descriptor and soffset are SGPR operands (s_nop 4 covers a
+// v_readfirstlane -> buffer hazard).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+__device__ __forceinline__ u32x4_t make_rsrc4(const void* p, uint32_t bytes) {
+    const uint64_t pa = (uint64_t)p;
+    u32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ void dma16_asm(u32x4_t r, const char* lds, uint32_t voff, uint32_t soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma4_asm(u32x4_t r, const char* lds, uint32_t voff, uint32_t soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ void flash_dma_tile(u32x4_t rk, u32x4_t rv, char* kdst, char* vdst,
                                                const uint32_t (&vk)[4], const uint32_t (&vv)[4], int wave, uint32_t ksoff,
                                                uint32_t vsoff) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (__attribute__((address_space(3))) void*)(kdst + (wave * 4 + i) * 1024), 16,
-                                                 (int)vk[i], (int)ksoff, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(vdst + (wave * 4 + i) * 1024), 16,
-                                                 (int)vv[i], (int)vsoff, 0, 0);
+        dma16_asm(rk, kdst + (wave * 4 + i) * 1024, vk[i], ksoff);
+        dma16_asm(rv, vdst + (wave * 4 + i) * 1024, vv[i], vsoff);
     }
 }
 
@@ -290,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         nkt = nkt < lim ? nkt : lim;
     }
     const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, (int)((uint32_t)(a.Sk - 1) * krow + 256u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, (int)((uint32_t)(a.Sk - 1) * vrow + 256u), 0x00020000);
+    const u32x4_t rk = make_rsrc4(kb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u)));
+    const u32x4_t rv = make_rsrc4(vb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u)));
     uint32_t vk[4], vv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -310,6 +346,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = zero16();
     if (nkt > 0) flash_dma_tile(rk, rv, smem, smem + 32768, vk, vv, wave, 0u, 0u);
+    // every load hipcc knows about (the register-resident fragments above) is retired HERE, through the builtin its scoreboard models:
+    // otherwise it re-issues its counted waits for them -- down to vmcnt(0) -- in front of the MFMAs of EVERY iteration, and those
+    // waits also drain the asm LDS-DMA of the next tile.  (vmcnt(0), expcnt / lgkmcnt untouched: simm16 0x0F70 on gfx9.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -726,8 +766,8 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
         nkt = nkt < lim ? nkt : lim;
     }
     const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
-    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kb), 0, (int)((uint32_t)(a.Sk - 1) * krow + 256u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vb), 0, (int)((uint32_t)(a.Sk - 1) * vrow + 256u), 0x00020000);
+    const u32x4_t rk = make_rsrc4(kb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u)));
+    const u32x4_t rv = make_rsrc4(vb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u)));
     uint32_t vk[4], vv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -743,6 +783,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = zero16();
     if (nkt > 0) flash_dma_tile(rk, rv, smem, smem + 32768, vk, vv, wave, 0u, 0u);
+    // every load hipcc knows about (the register-resident fragments above) is retired HERE, through the builtin its scoreboard models:
+    // otherwise it re-issues its counted waits for them -- down to vmcnt(0) -- in front of the MFMAs of EVERY iteration, and those
+    // waits also drain the asm LDS-DMA of the next tile.  (vmcnt(0), expcnt / lgkmcnt untouched: simm16 0x0F70 on gfx9.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -806,6 +850,7 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     // 3-stage ring, two query tiles in flight (a 32-row tile is only ~1k MFMA cycles of work, less than the DMA latency):
     // Q[3] | dO[3] (8 KB each) | lse2[3][64] | delta[3][64]
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    DSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // LPT: 1-D grid walked key block by key block -- under the causal mask key block 0 has the most query tiles, so the longest blocks
@@ -840,10 +885,10 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         qt0 = imin > 0 ? (imin >> 5) : 0;
     }
     const uint32_t qrow = (uint32_t)(a.qs.s * 2), dorow = (uint32_t)(a.dos.s * 2);
-    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(qb), 0, (int)((uint32_t)(a.Sq - 1) * qrow + 256u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(dob), 0, (int)((uint32_t)(a.Sq - 1) * dorow + 256u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rls = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lsb), 0, a.Sq * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rdl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dlb), 0, a.Sq * 4, 0x00020000);
+    const u32x4_t rq = make_rsrc4(qb, (uint32_t)((int)((uint32_t)(a.Sq - 1) * qrow + 256u)));
+    const u32x4_t rdo = make_rsrc4(dob, (uint32_t)((int)((uint32_t)(a.Sq - 1) * dorow + 256u)));
+    const u32x4_t rls = make_rsrc4(lsb, (uint32_t)(a.Sq * 4));
+    const u32x4_t rdl = make_rsrc4(dlb, (uint32_t)(a.Sq * 4));
     uint32_t vq[2], vd[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -855,14 +900,12 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     auto issue = [&](int qt, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(smem + buf * 8192 + (wave * 2 + i) * 1024), 16,
-                                                     (int)vq[i], (int)((uint32_t)qt * 32u * qrow), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdo, (__attribute__((address_space(3))) void*)(smem + 24576 + buf * 8192 + (wave * 2 + i) * 1024), 16,
-                                                     (int)vd[i], (int)((uint32_t)qt * 32u * dorow), 0, 0);
+            dma16_asm(rq, smem + buf * 8192 + (wave * 2 + i) * 1024, vq[i], (uint32_t)qt * 32u * qrow);
+            dma16_asm(rdo, smem + 24576 + buf * 8192 + (wave * 2 + i) * 1024, vd[i], (uint32_t)qt * 32u * dorow);
         }
         if (wave == 0) {  // 64 floats each (the upper 32 belong to the next tile; rows past Sq read as 0 and are masked)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rls, (__attribute__((address_space(3))) void*)(stat + buf * 256), 4, lane * 4, qt * 128, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdl, (__attribute__((address_space(3))) void*)(stat + 768 + buf * 256), 4, lane * 4, qt * 128, 0, 0);
+            dma4_asm(rls, stat + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
+            dma4_asm(rdl, stat + 768 + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
         }
     };
     const int qfo = ql * 256 + ((h2 ^ pi16(ql & 15)) << 4);
@@ -873,18 +916,36 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     for (int db = 0; db < 4; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
     if (qt0 < nqt) issue(qt0, 0);
     if (qt0 + 1 < nqt) issue(qt0 + 1, 1);
+    // every load hipcc knows about (the register-resident fragments above) is retired HERE, through the builtin its scoreboard models:
+    // otherwise it re-issues its counted waits for them -- down to vmcnt(0) -- in front of the MFMAs of EVERY iteration, and those
+    // waits also drain the asm LDS-DMA of the next tile.  (vmcnt(0), expcnt / lgkmcnt untouched: simm16 0x0F70 on gfx9.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // Software pipeline (one wave per SIMD: nothing else covers a latency).  Per tile t:
+    //   top     transpose reads of tile t issued (they land under the S / dP MFMAs)
+    //           S / dP MFMAs of tile t -- their row fragments were read during the previous iteration's dV / dK MFMAs;
+    //           the DMA of tile t+2 is issued into the slot of tile t-1 while the matrix pipe works through the queue
+    //           softmax of tile t (VALU)
+    //   middle  counted wait for the DMA of tile t+1 + barrier (every wave has also finished READING tile t: lgkmcnt(0) first)
+    //           row-fragment reads of tile t+1 issued (they land under ...)
+    //   bottom  dV / dK MFMAs of tile t
+    // The barrier that opens the loop in the straightforward form moved to the middle; tile t's slot is dead after it.
+    bf16x8_t qr[8], dr[8];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // prologue: both tiles (the builtin wait above covers them anyway)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+        const char* Qn = smem;
+        const char* Dn = smem + 24576;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            qr[c] = *reinterpret_cast<const bf16x8_t*>(Qn + (qfo ^ (32 * c)));
+            dr[c] = *reinterpret_cast<const bf16x8_t*>(Dn + (qfo ^ (32 * c)));
+        }
+    }
     int cur = 0;
     for (int qt = qt0; qt < nqt; ++qt, cur = cur == 2 ? 0 : cur + 1) {
-        // tile qt has landed when at most the pieces of tile qt+1 are outstanding (wave 0 also carries the two statistics pieces)
-        if (qt + 1 < nqt) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done with tile qt-1, whose slot is refilled next
-        asm volatile("" ::: "memory");
-        if (qt + 2 < nqt) issue(qt + 2, cur == 0 ? 2 : cur - 1);
+        DSTAMP(1 + 5 * (qt - qt0));
+        DSTAMP(2 + 5 * (qt - qt0));
         const int i0 = qt * 32;
         // (no per-wave skip of tiles that precede the wave's keys: the branch makes hipcc shuttle the 128 accumulator
         //  registers between VGPRs and AGPRs on every iteration, which costs more than the <= 3 masked tiles it saves)
@@ -892,26 +953,102 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         const char* Dc = smem + 24576 + cur * 8192;
         const float* lse_s = reinterpret_cast<const float*>(stat + cur * 256);
         const float* dl_s = reinterpret_cast<const float*>(stat + 768 + cur * 256);
-        f32x16_t s = zero16(), dp = zero16();
+        // All LDS reads of the tile are issued up front (48 per wave: 16 row fragments for S / dP, 32 transpose reads for dV / dK; 128
+        // registers of fragments -- one wave per SIMD has them): the timeline (tools/flash_timeline_dkv.py) showed the MFMAs of both
+        // phases waiting on ds_read latency one fragment at a time (3 900 cycles per tile against 1 024 of MFMA work).
+        bf16x8_t tD[2][4], tQ[2][4];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Qc + (qfo ^ (32 * c))), kf[c], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Dc + (qfo ^ (32 * c))), vf[c], dp, 0, 0, 0);
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                tD[c][db] = tr_pi_frag(Dc, to1, to2, db, 16 * c);
+                tQ[c][db] = tr_pi_frag(Qc, to1, to2, db, 16 * c);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // S^T and dP^T accumulate in VGPRs through asm MFMAs: with the builtin hipcc puts them in a[0:31], which hold a quarter of the
+        // dK / dV accumulators, and moves those 32 registers out to VGPRs and back around them on every tile (96 v_accvgpr_* per
+        // iteration; the softmax would read s / dp out of AGPRs one by one as well).  Hazards the assembler does not pad: a leading
+        // s_nop 1 (VALU / LDS-written operand -> MFMA), and 18 wait states after the last MFMA before the softmax reads the results.
+        f32x16_t s, dp;
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(qr[0]), "v"(kf[0]));
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dp) : "v"(dr[0]), "v"(vf[0]));
+#pragma unroll
+        for (int c = 1; c < 8; ++c) {
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(qr[c]), "v"(kf[c]));
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dp) : "v"(dr[c]), "v"(vf[c]));
+            // the DMA of tile qt+2 (into the slot of tile qt-1, which every wave left before the barrier above) is issued while the matrix
+            // pipe works through the queue: an LDS-DMA piece costs ~80 cycles of issue that would otherwise sit between two phases
+            if (c == 3 && qt + 2 < nqt) issue(qt + 2, cur == 0 ? 2 : cur - 1);
         }
-        const bool interior = i0 + 31 < a.Sq && (!a.causal || kw + 31 <= i0 + off);  // whole 32x32 block visible (key validity is per lane)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s), "+v"(dp));
+        DSTAMP(3 + 5 * (qt - qt0));
+        // Visibility of query row i0 + idx (idx = 8g + 4h2 + e) for this lane's key: lo <= idx < hi.  One unsigned compare and one
+        // v_cndmask per element, no control flow: the short-circuit form `kok && (interior || (i < Sq && (!causal || kj <= i + off)))`
+        // compiled into 29 EXEC-mask branches per iteration, which also kept the scheduler from moving anything across them.
+        // Interior tiles (every row below Sq and at or past the wave's last key; no key-padding mask) skip the mask arithmetic.
+        const bool interior = i0 + 31 < a.Sq && (!a.causal || kw + 31 <= i0 + off);  // wave-uniform
+        if (interior && a.kvalid == nullptr) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
-            const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
-            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                const int i = i0 + 8 * g + 4 * h2 + e;
-                const bool ok = kok && (interior || (i < a.Sq && (!a.causal || kj <= i + off)));
-                const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc2, bias2 - lv[e])) : 0.f;
-                s[r] = p;
-                dp[r] = p * (dp[r] - dvv[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, bias2 - lv[e]));
+                    s[r] = p;
+                    dp[r] = p * (dp[r] - dvv[e]);
+                }
+            }
+        } else {
+            int lo = 0, hi = 32;
+            if (!interior) {
+                const int vis = a.causal ? kj - off - i0 : 0;     // first visible row, relative to the tile
+                lo = vis > 0 ? vis : 0;
+                hi = a.Sq - i0 < 32 ? a.Sq - i0 : 32;
+            }
+            if (!kok) hi = 0;
+            const unsigned span = hi > lo ? (unsigned)(hi - lo) : 0u;
+            const int idx0 = 4 * h2 - lo;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const bool ok = (unsigned)(idx0 + 8 * g + e) < span;
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, bias2 - lv[e]));
+                    const float p = ok ? pe : 0.f;
+                    s[r] = p;
+                    dp[r] = p * (dp[r] - dvv[e]);
+                }
+            }
+        }
+#ifdef OTTER_FLASH_TIMING
+        asm volatile("" :: "v"(s[15]), "v"(dp[15]));
+#endif
+        DSTAMP(4 + 5 * (qt - qt0));
+        if (qt + 1 < nqt) {
+            // tile qt+1 has landed when at most the pieces of tile qt+2 are outstanding (wave 0 also carries the two statistics pieces);
+            // lgkmcnt(0): this wave's LDS reads of tile qt (transpose reads, lse / delta) have returned, so after the barrier its slot is dead
+            if (qt + 2 < nqt) {
+                if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int nx = cur == 2 ? 0 : cur + 1;
+            const char* Qn = smem + nx * 8192;
+            const char* Dn = smem + 24576 + nx * 8192;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                qr[c] = *reinterpret_cast<const bf16x8_t*>(Qn + (qfo ^ (32 * c)));
+                dr[c] = *reinterpret_cast<const bf16x8_t*>(Dn + (qfo ^ (32 * c)));
             }
         }
 #pragma unroll
@@ -919,15 +1056,23 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
             const bf16x8_t pf = pack8(s, 8 * c), dsf = pack8(dp, 8 * c);
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Dc, to1, to2, db, 16 * c), pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Qc, to1, to2, db, 16 * c), dsf, dk[db], 0, 0, 0);
+                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tD[c][db], pf, dv[db], 0, 0, 0);
+                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tQ[c][db], dsf, dk[db], 0, 0, 0);
             }
         }
+        DSTAMP(5 + 5 * (qt - qt0));
     }
+    DSTAMP(90);
     if (kj < a.Sk) {
         store_dt(a.dk + b * a.dks.b + hd * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, h2);
         store_dt(a.dv + b * a.dvs.b + hd * a.dvs.h + (int64_t)kj * a.dvs.s, dv, 1.0f, h2);
     }
+#ifdef OTTER_FLASH_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DSTAMP(91);
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 96 && g_flash_stamps) g_flash_stamps[threadIdx.x] = reinterpret_cast<unsigned long long*>(smem + 50688)[threadIdx.x];
+#endif
 }
 
 int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
@@ -1016,7 +1161,11 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
     const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < lim && (int64_t)a.Sk * a.vs.s * 2 < lim &&
                     (int64_t)a.Sq * a.qs.s * 2 < lim && (int64_t)a.Sq * a.dos.s * 2 < lim;
     if (v2) {
+        #ifdef OTTER_FLASH_TIMING
+        const int smem_kv = 49152 + 1536 + 1024, smem_q = 65536;
+#else
         const int smem_kv = 49152 + 1536, smem_q = 65536;
+#endif
         static bool once = false;
         if (!once) {
             rc = set_smem(flash_bwd_dkv2_kernel<1, false>, smem_kv); if (rc) return rc;

@@ -1,0 +1,34 @@
+"""In-kernel timeline (s_memtime ticks, 100 MHz -> 10 ns each) of the first dK/dV workgroup (key block 0: 16 query tiles at S=512) of the
+decoder-host flash attention backward.  Needs `python -m otter_amd.build --flash-timing` and
+OTTER_LIB_PATH=otter_amd/lib/libotter_hip_flashtiming.so."""
+import ctypes, json, math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from otter_amd import ops, _capi
+from otter_amd.mpt import alibi_slopes
+
+B, S, H = 8, 512, 32
+qkv = torch.randn(B, S, 3, H, 128, device="cuda").to(torch.bfloat16)
+dout = torch.randn(B, S, H, 128, device="cuda").to(torch.bfloat16)
+sl = alibi_slopes(H, 8).float().cuda()
+st = torch.zeros(96, dtype=torch.int64, device="cuda")
+lib = _capi.lib()
+lib.otter_flash_set_stamps.argtypes = [ctypes.c_void_p]
+assert lib.otter_flash_set_stamps(st.data_ptr()) == 0
+q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+scale = 1 / math.sqrt(128)
+o, lse = ops.flash_attn_fwd(q, k, v, sl, None, scale, True)
+dqkv = torch.empty_like(qkv)
+for _ in range(3):
+    ops.flash_attn_bwd(q, k, v, o, lse, dout, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], sl, None, scale, True)
+torch.cuda.synchronize()
+t = st.cpu().tolist()
+rel = lambda i: t[i] - t[0]
+rows = []
+for it in range(16):
+    b = 1 + 5 * it
+    rows.append({"it": it, "top": rel(b), "wait+barrier": t[b + 1] - t[b], "reads+S,dP+dma": t[b + 2] - t[b + 1], "softmax": t[b + 3] - t[b + 2],
+                 "dV,dK": t[b + 4] - t[b + 3]})
+print(json.dumps({"prologue_to_loop": rel(1), "loop_end": rel(90), "stores_done": rel(91)}))
+for r in rows:
+    print(json.dumps(r))
