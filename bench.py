@@ -252,6 +252,54 @@ def cpu_baseline(T=512):
     return {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
 
 
+def gated_block_roofline(model, batch, B, T, device, iters=10):
+    """North-star figure: one OtterGatedCrossAttentionBlock (the model's first one, its real weights) forward + backward at the bench
+    shapes, timed stand-alone with events (outside the timed steps), against SURVEY.md 8d's 141.94 GF per 512-token sample and forward
+    (x 3 for forward + dgrad + wgrad) and the 2.5 PF dense bf16 peak.  Includes everything the block launches: LayerNorms, cross
+    attention, the six FFN-shape GEMMs with their fused tails, the small projections, operand transposes, fp32 weight gradients."""
+    blk = None
+    for layer in model.lang_encoder._get_decoder_layers():
+        if getattr(layer, "gated_cross_attn_layer", None) is not None:
+            blk = layer.gated_cross_attn_layer
+            break
+    if blk is None:
+        return None
+    _, ids, _, _ = batch
+    D = blk.feed_forward[1].weight.shape[1]
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.randn(B, T, D, device=device, generator=g).requires_grad_(True)
+    media = torch.randn(B, 1, 64, blk.attn.to_kv.weight.shape[1], device=device, generator=g)
+    dy = torch.randn(B, T, D, device=device, generator=g)
+    ml = ids == model.media_token_id
+    saved = [(p, p.grad) for p in blk.parameters()]
+
+    def once():
+        for p, _ in saved:
+            p.grad = None        # as after zero_grad(set_to_none=True): the weight gradients are written, not accumulated
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(x, media, media_locations=ml, attend_previous=True)
+        y.backward(dy)
+
+    for _ in range(2):
+        once()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        once()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    for p, gsave in saved:
+        p.grad = gsave
+    x.grad = None
+    Tm = 64
+    fwd = 2.0 * T * (D * 512 + 512 * D + 2 * D * 4 * D) + 2.0 * Tm * media.shape[-1] * 1024 + 4.0 * T * Tm * 512   # per sample (SURVEY 8d)
+    ach = 3.0 * fwd * B / (ms * 1e-3) / 1e12
+    return {"what": "one gated cross-attention block, forward + backward, B=%d x %d tokens, stand-alone" % (B, T), "ms": round(ms, 3),
+            "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +312,7 @@ def main():
                          "c5 = OtterHD / Fuyu-8B full fine-tune, 1080x1080 patch tokens (configs[4]; batch 8 as in the reference's OtterHD recipe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-variant", type=int, default=0)
+    ap.add_argument("--flash-variant", type=int, default=0, help="A/B hook: otter_flash_set_variant (2 = plain grid order instead of longest-first)")
     ap.add_argument("--debug-layers", type=int, default=0, help="DEBUG ONLY: shrink MPT to this many layers (not a valid bench)")
     args = ap.parse_args()
 
@@ -292,6 +341,8 @@ def main():
 
     if args.gemm_variant:
         ops.set_gemm_variant(args.gemm_variant)
+    if args.flash_variant:
+        ops.set_flash_variant(args.flash_variant)
     model = build_model(device, seed=0, debug_layers=args.debug_layers, config=args.config)  # identical replica on every rank (same seed)
     step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16,
                      force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1")
@@ -341,6 +392,8 @@ def main():
             roof = {"bound": "mfma", "kernel": "%s M=%d N=%d K=%d" % (names.get(v, "gemm variant %d" % v), M, N, Kd), "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
+            if world == 1 and os.environ.get("OTTER_FORCE_DIST") != "1":   # (no DP reducer hooks on the parameters: stand-alone backward is safe)
+                roof["gated_block"] = gated_block_roofline(model, batch, B, T, device)
         out = {
             "metric": ("image-text pairs/s (train step) OTTER-MPT7B, 1 img+512 tok" if args.config == "c2"
                        else "video-text pairs/s (train step) OTTER-Video-LLaMA7B, 8 frames+512 tok"),
