@@ -76,6 +76,54 @@ def test_layernorm_fwd_bwd(ops, rows, D, dt):
     assert relmax(host(dg), dw_ref) < 1e-4 and relmax(host(db), db_ref) < 1e-4
 
 
+@pytest.mark.parametrize("rows,D", [(37, 512), (130, 1024), (70, 4096), (4097, 1536)])
+def test_norm_training_config_vs_oracle(ops, rows, D):
+    """The coalesced row kernels (fp32 stream, bf16 branch tensors, D % 512 == 0: norm_fwd_c / norm_bwd_dx_c_kernel) against the oracle:
+    LayerNorm forward (plain, with fused residual add, through a row map + second output), backward with and without the residual
+    gradient / bf16 copy / weight gradients; RMSNorm forward + backward.  Tolerances: bf16 outputs 1e-2, fp32 results 5e-5."""
+    from otter_amd._capi import RowMap
+
+    r = rng(rows + D)
+    x = (r.standard_normal((rows, D)) * 2 + 0.5).astype(np.float32)
+    w = (1 + 0.1 * r.standard_normal(D)).astype(np.float32)
+    b = (0.1 * r.standard_normal(D)).astype(np.float32)
+    dy = bf16_round(r.standard_normal((rows, D)))
+    dres = r.standard_normal((rows, D)).astype(np.float32)
+    delta = bf16_round(r.standard_normal((rows, D)))
+    # forward
+    y_ref, cache = O.layer_norm_fwd(x, w, b)
+    y, mean, rstd = ops.layernorm_fwd(to_dev(x), to_dev(w), to_dev(b), torch.bfloat16)
+    assert y.dtype == torch.bfloat16 and relmax(host(y), y_ref) < 1e-2
+    assert relmax(host(mean), x.mean(-1)) < 1e-5 and relmax(host(rstd), cache[1][:, 0]) < 1e-4
+    xs, y2, mean2, rstd2 = ops.add_layernorm_fwd(to_dev(x), to_dev(delta, torch.bfloat16), to_dev(w), to_dev(b), torch.bfloat16)
+    ys_ref, cache_s = O.layer_norm_fwd(x + delta, w, b)
+    assert np.array_equal(host(xs), x + delta) and relmax(host(y2), ys_ref) < 1e-2
+    if rows % 2 == 0:   # row-mapped output + the second (contiguous) copy
+        half = rows // 2
+        buf = torch.zeros((rows + 6, D), dtype=torch.bfloat16, device=DEV)
+        ycopy = torch.empty((rows, D), dtype=torch.bfloat16, device=DEV)
+        ops.layernorm_fwd(to_dev(x), to_dev(w), to_dev(b), torch.bfloat16, y=buf, ymap=RowMap(half, half + 3, 3), y2=ycopy)
+        got = host(buf).reshape(2, half + 3, D)[:, 3:, :].reshape(rows, D)
+        assert np.array_equal(got, host(y)) and torch.equal(ycopy, y)
+    # backward: dx (+ residual gradient), bf16 copy, weight gradients
+    dx_ref, dw_ref, db_ref = O.layer_norm_bwd(dy, cache)
+    dxb = torch.empty((rows, D), dtype=torch.bfloat16, device=DEV)
+    dx, dg, db = ops.layernorm_bwd(to_dev(dy, torch.bfloat16), to_dev(x), to_dev(w), mean, rstd, torch.float32, dres=to_dev(dres), dx_bf16=dxb)
+    assert relmax(host(dx), dx_ref + dres) < 5e-5 and torch.equal(dxb, dx.to(torch.bfloat16))
+    assert relmax(host(dg), dw_ref) < 1e-4 and relmax(host(db), db_ref) < 1e-4
+    dx0, _, _ = ops.layernorm_bwd(to_dev(dy, torch.bfloat16), to_dev(x), to_dev(w), mean, rstd, torch.float32, need_dw=False)
+    assert relmax(host(dx0), dx_ref) < 5e-5
+    dxn, _, _ = ops.layernorm_bwd(to_dev(dy, torch.bfloat16), to_dev(x), None, mean, rstd, torch.float32, need_dw=False)   # no affine
+    assert relmax(host(dxn), O.layer_norm_bwd(dy, (cache[0], cache[1], None))[0]) < 5e-5
+    # RMSNorm (LLaMA host): fp32 stream, bf16 out; backward with residual gradient and weight gradient
+    xs2, yr, rs = ops.add_rmsnorm_fwd(to_dev(x), to_dev(delta, torch.bfloat16), to_dev(w), torch.bfloat16)
+    yr_ref, c = O.rms_norm_fwd(x + delta, w, 1e-6)
+    assert np.array_equal(host(xs2), x + delta) and relmax(host(yr), yr_ref) < 1e-2
+    dxr_ref, dwr_ref = O.rms_norm_bwd(dy, c)
+    dxr, dwr = ops.rmsnorm_bwd_ex(to_dev(dy, torch.bfloat16), xs2, to_dev(w), rs, torch.float32, dres=to_dev(dres), need_dw=True)
+    assert relmax(host(dxr), dxr_ref + dres) < 5e-5 and relmax(host(dwr), dwr_ref) < 1e-4
+
+
 def test_layernorm_rowmap_and_nobias(ops):
     from otter_amd._capi import RowMap
 
