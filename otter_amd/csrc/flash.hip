@@ -31,6 +31,7 @@ typedef short s16x8_t __attribute__((ext_vector_type(8)));
 
 constexpr int HD = 128;       // head dim
 constexpr int LDK = HD + 8;   // row-fragment tiles (272-B rows)
+constexpr int KMASK_TILES = 128;  // v2 forward / dQ: key-padding masks of up to 128 key tiles (Sk <= 8192) live in LDS
 constexpr int LDT = HD + 32;  // transpose-read tiles (320-B rows)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -345,6 +346,18 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     f32x16_t o[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = zero16();
+    // Key-padding masks: one 64-bit word per key tile, parked behind the tile buffers.  Reading the validity bytes inside the loop is a
+    // load hipcc counts: it waits vmcnt(0) for it, which also drains the asm LDS-DMA of the next tile (every padded batch paid that).
+    unsigned long long* const kmask = reinterpret_cast<unsigned long long*>(smem + 65536);
+    const bool kmask_lds = kv != nullptr && nkt <= KMASK_TILES;
+    if (kmask_lds) {
+        for (int t = wave; t < nkt; t += 4) {
+            const int jj = t * 64 + lane;
+            const unsigned long long mk = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0);
+            if (lane == 0) kmask[t] = mk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first barrier of the loop
+    }
     if (nkt > 0) flash_dma_tile(rk, rv, smem, smem + 32768, vk, vv, wave, 0u, 0u);
     // every load hipcc knows about (the register-resident fragments above) is retired HERE, through the builtin its scoreboard models:
     // otherwise it re-issues its counted waits for them -- down to vmcnt(0) -- in front of the MFMAs of EVERY iteration, and those
@@ -389,7 +402,9 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
             const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
             const int limh = (a.causal && rel < kend ? rel : kend) - 4 * h2;
             unsigned long long vmh = ~0ull;
-            if (kv) {
+            if (kmask_lds) {
+                vmh = kmask[kt] >> (4 * h2);
+            } else if (kv) {
                 const int jj = k0 + lane;
                 vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
             }
@@ -782,6 +797,18 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
     f32x16_t dq[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) dq[db] = zero16();
+    // Key-padding masks: one 64-bit word per key tile, parked behind the tile buffers.  Reading the validity bytes inside the loop is a
+    // load hipcc counts: it waits vmcnt(0) for it, which also drains the asm LDS-DMA of the next tile (every padded batch paid that).
+    unsigned long long* const kmask = reinterpret_cast<unsigned long long*>(smem + 65536);
+    const bool kmask_lds = kv != nullptr && nkt <= KMASK_TILES;
+    if (kmask_lds) {
+        for (int t = wave; t < nkt; t += 4) {
+            const int jj = t * 64 + lane;
+            const unsigned long long mk = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0);
+            if (lane == 0) kmask[t] = mk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first barrier of the loop
+    }
     if (nkt > 0) flash_dma_tile(rk, rv, smem, smem + 32768, vk, vv, wave, 0u, 0u);
     // every load hipcc knows about (the register-resident fragments above) is retired HERE, through the builtin its scoreboard models:
     // otherwise it re-issues its counted waits for them -- down to vmcnt(0) -- in front of the MFMAs of EVERY iteration, and those
@@ -805,7 +832,9 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
         const float base = sl2 * (float)(k0 + 4 * h2 - (a.Sk - 1)) - lse2;
         const bool interior = kv == nullptr && k0 + 63 < a.Sk && (!a.causal || k0 + 63 <= wq0);
         unsigned long long vmh = ~0ull;
-        if (kv) {
+        if (kmask_lds) {
+            vmh = kmask[kt] >> (4 * h2);
+        } else if (kv) {
             const int jj = k0 + lane;
             vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
         }
@@ -1129,7 +1158,7 @@ int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
     // the DMA path addresses a head's K / V with 32-bit offsets from its base
     const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < (int64_t(1) << 31) && (int64_t)a.Sk * a.vs.s * 2 < (int64_t(1) << 31);
     if (v2) {
-        const int smem = 65536;
+        const int smem = 65536 + KMASK_TILES * 8;
         static bool once = false;
         if (!once) {
             rc = set_smem(flash_fwd2_kernel<false>, smem); if (rc) return rc;
@@ -1162,9 +1191,9 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
                     (int64_t)a.Sq * a.qs.s * 2 < lim && (int64_t)a.Sq * a.dos.s * 2 < lim;
     if (v2) {
         #ifdef OTTER_FLASH_TIMING
-        const int smem_kv = 49152 + 1536 + 1024, smem_q = 65536;
+        const int smem_kv = 49152 + 1536 + 1024, smem_q = 65536 + KMASK_TILES * 8;
 #else
-        const int smem_kv = 49152 + 1536, smem_q = 65536;
+        const int smem_kv = 49152 + 1536, smem_q = 65536 + KMASK_TILES * 8;
 #endif
         static bool once = false;
         if (!once) {

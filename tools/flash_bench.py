@@ -1,5 +1,5 @@
 """Decoder-host attention at the C2 shape (B=8, 32 heads x 128, 512 tokens, causal + ALiBi): HIP flash kernels vs the
-additive-mask SDPA path they replace.  Usage: flash_bench.py [B] [S]"""
+additive-mask SDPA path they replace.  Usage: flash_bench.py [B] [S] [causal] [sdpa] [padded]"""
 import json, math, os, sys
 import torch
 import torch.nn.functional as F
@@ -11,6 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 CAUSAL = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
 SDPA = bool(int(sys.argv[4])) if len(sys.argv) > 4 else True
+PAD = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False   # right-padded batch: key_valid mask with lengths in [S/2, S]
 H = 32
 
 def bench(fn, iters=20):
@@ -26,12 +27,17 @@ dout = torch.randn(B, S, H, 128, device="cuda").to(torch.bfloat16)
 sl = alibi_slopes(H, 8).float().cuda()
 scale = 1 / math.sqrt(128)
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-o, lse = ops.flash_attn_fwd(q, k, v, sl, None, scale, CAUSAL)
+KV = None
+if PAD:
+    lens = torch.randint(S // 2, S + 1, (B,), device="cuda")
+    KV = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).to(torch.uint8).contiguous()
+o, lse = ops.flash_attn_fwd(q, k, v, sl, KV, scale, CAUSAL)
 dqkv = torch.empty_like(qkv)
 ops.set_flash_variant(int(os.environ.get("FLASH_VARIANT", "0")))
 res = {"B": B, "S": S, "H": H, "causal": CAUSAL, "variant": int(os.environ.get("FLASH_VARIANT", "0"))}
-res["hip_fwd_us"] = bench(lambda: ops.flash_attn_fwd(q, k, v, sl, None, scale, CAUSAL))
-res["hip_bwd_us"] = bench(lambda: ops.flash_attn_bwd(q, k, v, o, lse, dout, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], sl, None, scale, CAUSAL))
+res["padded"] = PAD
+res["hip_fwd_us"] = bench(lambda: ops.flash_attn_fwd(q, k, v, sl, KV, scale, CAUSAL))
+res["hip_bwd_us"] = bench(lambda: ops.flash_attn_bwd(q, k, v, o, lse, dout, dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], sl, KV, scale, CAUSAL))
 fl = 4 * B * H * S * S * 128 * (0.5 if CAUSAL else 1.0)
 res["hip_fwd_TF"] = fl / res["hip_fwd_us"] / 1e6
 res["hip_bwd_TF"] = 2.5 * fl / res["hip_bwd_us"] / 1e6
