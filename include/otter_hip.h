@@ -309,7 +309,8 @@ int otter_scatter_rows(const void* word, int word_dtype, const void* patch, int 
  * ignore_index = -100 and mean reduction     /root/reference/src/otter_ai/models/mpt/modeling_mpt.py:428-435
  * (the caller rolls the labels).  fwd: lse[r], nll[r] (0 for ignored rows) from one read of the logits; the mean
  * is sum(nll) / max(n_valid, 1).  bwd: dlogits (bf16) = (softmax - onehot) * (*dloss) / max(*n_valid, 1), zero rows for
- * ignored labels; dloss and n_valid are device scalars (no host synchronisation).
+ * ignored labels; dloss and n_valid are device scalars (no host synchronisation).  Row strides: multiples of 4 elements (16-byte
+ * accesses when they are multiples of 8 and the bases 16-byte aligned, 8-byte accesses otherwise -- LLaMA's 32004-wide vocabulary).
  * ------------------------------------------------------------------------------------------------------- */
 int otter_cross_entropy_fwd(const void* logits, int64_t ld, const int64_t* labels, float* lse, float* nll, int64_t rows, int64_t V,
                             void* stream);

@@ -269,7 +269,7 @@ class PersimmonForCausalLM(PersimmonPreTrainedModel):
             lab = torch.full_like(labels, -100)
             lab[:, :-1] = labels[:, 1:]
             flat, lab = logits.view(-1, logits.size(-1)), lab.to(logits.device).view(-1)
-            if flat.is_cuda and flat.dtype == torch.bfloat16 and flat.size(-1) % 8 == 0 and os.environ.get("OTTER_TORCH_CE") != "1":
+            if flat.is_cuda and flat.dtype == torch.bfloat16 and flat.size(-1) % 4 == 0 and os.environ.get("OTTER_TORCH_CE") != "1":
                 loss = OF.cross_entropy_bf16(flat, lab)
             else:
                 loss = F.cross_entropy(flat.float(), lab, ignore_index=-100)

@@ -403,7 +403,7 @@ class MPTForCausalLM(MPTPreTrainedModel):
             _labels = torch.roll(labels, shifts=-1)      # flat roll, exactly as modeling_mpt.py:428-435
             _labels[:, -1] = -100
             flat, lab = logits.view(-1, logits.size(-1)), _labels.to(logits.device).view(-1)
-            if flat.is_cuda and flat.dtype == torch.bfloat16 and flat.size(-1) % 8 == 0 and os.environ.get("OTTER_TORCH_CE") != "1":
+            if flat.is_cuda and flat.dtype == torch.bfloat16 and flat.size(-1) % 4 == 0 and os.environ.get("OTTER_TORCH_CE") != "1":
                 loss = OF.cross_entropy_bf16(flat, lab.contiguous())   # one pass over the bf16 logits (csrc/loss.hip)
             else:
                 loss = F.cross_entropy(flat.float(), lab)
