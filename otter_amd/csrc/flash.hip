@@ -69,9 +69,17 @@ __device__ unsigned long long* g_flash_stamps = nullptr;
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                 \
         if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 96) reinterpret_cast<unsigned long long*>(smem + 50688)[slot] = t_; \
     } while (0)
+// forward (v2): same, its own LDS area (behind the key-padding masks) and output slots 96..191
+#define FSTAMP(slot)                                                                                              \
+    do {                                                                                                          \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                 \
+        if (LPT && blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 96) reinterpret_cast<unsigned long long*>(smem + 65536 + 1024)[slot] = t_; \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
 #define DSTAMP(slot) do {} while (0)
+#define FSTAMP(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ f32x16_t zero16() {
@@ -363,14 +371,18 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     // otherwise it re-issues its counted waits for them -- down to vmcnt(0) -- in front of the MFMAs of EVERY iteration, and those
     // waits also drain the asm LDS-DMA of the next tile.  (vmcnt(0), expcnt / lgkmcnt untouched: simm16 0x0F70 on gfx9.)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    FSTAMP(0);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
+        FSTAMP(1 + 5 * kt);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave; every wave is done with tile kt-1
         asm volatile("" ::: "memory");
+        FSTAMP(2 + 5 * kt);
         if (kt + 1 < nkt)
             flash_dma_tile(rk, rv, smem + (cur ^ 1) * 16384, smem + 32768 + (cur ^ 1) * 16384, vk, vv, wave, (uint32_t)(kt + 1) * 64u * krow,
                            (uint32_t)(kt + 1) * 64u * vrow);
+        FSTAMP(3 + 5 * kt);
         const int k0 = kt * 64;
         const int wq0 = q0 + wave * 32 + off;  // first query of the wave, in key coordinates
         if (a.causal && k0 > wq0 + 31) continue;  // whole tile above this wave's diagonal
@@ -442,6 +454,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
                 s[kbk][r] = p;
                 lsum += p;
             }
+#ifdef OTTER_FLASH_TIMING
+        asm volatile("" :: "v"(s[1][15]), "v"(lsum));
+#endif
+        FSTAMP(4 + 5 * kt);
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
@@ -456,13 +472,21 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vfr), pf, o[db], 0, 0, 0);
                 }
             }
+        FSTAMP(5 + 5 * kt);
     }
+    FSTAMP(90);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
     if (qi < a.Sq) {
         store_dt(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s, o, inv, h2);
         if (h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
     }
+#ifdef OTTER_FLASH_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FSTAMP(91);
+    __syncthreads();
+    if (LPT && blockIdx.x == 0 && threadIdx.x < 96 && g_flash_stamps) g_flash_stamps[96 + threadIdx.x] = reinterpret_cast<unsigned long long*>(smem + 65536 + 1024)[threadIdx.x];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1158,7 +1182,11 @@ int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
     // the DMA path addresses a head's K / V with 32-bit offsets from its base
     const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < (int64_t(1) << 31) && (int64_t)a.Sk * a.vs.s * 2 < (int64_t(1) << 31);
     if (v2) {
+#ifdef OTTER_FLASH_TIMING
+        const int smem = 65536 + KMASK_TILES * 8 + 1024;
+#else
         const int smem = 65536 + KMASK_TILES * 8;
+#endif
         static bool once = false;
         if (!once) {
             rc = set_smem(flash_fwd2_kernel<false>, smem); if (rc) return rc;

@@ -11,7 +11,7 @@ B, S, H = 8, 512, 32
 qkv = torch.randn(B, S, 3, H, 128, device="cuda").to(torch.bfloat16)
 dout = torch.randn(B, S, H, 128, device="cuda").to(torch.bfloat16)
 sl = alibi_slopes(H, 8).float().cuda()
-st = torch.zeros(96, dtype=torch.int64, device="cuda")
+st = torch.zeros(192, dtype=torch.int64, device="cuda")
 lib = _capi.lib()
 lib.otter_flash_set_stamps.argtypes = [ctypes.c_void_p]
 assert lib.otter_flash_set_stamps(st.data_ptr()) == 0
@@ -32,3 +32,9 @@ for it in range(16):
 print(json.dumps({"prologue_to_loop": rel(1), "loop_end": rel(90), "stores_done": rel(91)}))
 for r in rows:
     print(json.dumps(r))
+# forward (v2), block 0 = the last query tile of (batch 0, head 0): 8 key tiles
+f = t[96:]
+print(json.dumps({"fwd_prologue": f[1] - f[0], "fwd_loop_end": f[90] - f[0], "fwd_stores_done": f[91] - f[0]}))
+for kt in range(8):
+    b = 1 + 5 * kt
+    print(json.dumps({"kt": kt, "top": f[b] - f[0], "wait+barrier": f[b + 1] - f[b], "dma_issue": f[b + 2] - f[b + 1], "S+softmax": f[b + 3] - f[b + 2], "PV": f[b + 4] - f[b + 3]}))
