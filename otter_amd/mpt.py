@@ -101,18 +101,29 @@ class _Norm(nn.LayerNorm):
         return OF.add_layer_norm(x, delta, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
 
 
+_OWN_GEMM = os.environ.get("OTTER_OWN_DECODER_GEMM") == "1"   # A/B hook: the frozen decoder's GEMMs on csrc/gemm.hip instead of hipBLASLt
+
+
+def _lin(x, w):
+    if _OWN_GEMM and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
+        from . import ops
+        x2 = x.reshape(-1, x.shape[-1])
+        return ops.gemm_nt(x2 if x2.is_contiguous() else x2.contiguous(), w).view(x.shape[:-1] + (w.shape[0],))
+    return F.linear(x, w)
+
+
 class _FrozenLinearFn(torch.autograd.Function):
     """y = x W^T whose input gradient is computed against a stored transposed copy of the (frozen) weight."""
 
     @staticmethod
     def forward(ctx, x, w, wt):
         ctx.save_for_backward(wt)
-        return F.linear(x, w)
+        return _lin(x, w)
 
     @staticmethod
     def backward(ctx, dy):
         (wt,) = ctx.saved_tensors
-        return F.linear(dy, wt), None, None
+        return _lin(dy, wt), None, None
 
 
 class FrozenAwareLinear(nn.Linear):
