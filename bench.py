@@ -163,7 +163,9 @@ def run_c5(args, device, rank, world, use_dist):
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
             "loss": round(float(loss), 4),
             "model_tflops_per_s": round(flops * args.steps / elapsed / 1e12, 1),
-            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)
+            "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+            "reserved_mem_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1),
+            "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))}), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

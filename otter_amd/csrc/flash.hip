@@ -49,6 +49,7 @@ struct FlashArgs {
     const bf16_t* dout; Str dos;
     float* delta;          // [B, H, Sq]
     bf16_t* dq; bf16_t* dk; bf16_t* dv; Str dqs, dks, dvs;
+    int lpt_group;         // heads per group of the longest-first block order (divides B*H)
 };
 
 // In-kernel timeline of workgroup (3,0,0) / wave 0 of the forward (diagnostics build only: -DOTTER_FLASH_TIMING)
@@ -278,6 +279,20 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashArgs a) {
 // destination) is saved and restored inside the statement; the descriptor and soffset are SGPR operands (s_nop 4 covers a
 // v_readfirstlane -> buffer hazard).
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+// Longest-first block order in groups of G heads (a.lpt_group): 1-D block index -> (group, rank inside the head, head).  Inside a group the
+// blocks are walked rank by rank (rank 0 = the longest block of every head), so the launch never ends on a long block; the group keeps
+// the K / V (or Q / dO) panels that the blocks of one head share to what the L2 + Infinity Cache hold -- with ONE group over 512 heads
+// of 1 396 tokens (config C5) every concurrently running block belonged to a different head and the forward re-read K / V from HBM for
+// each of its 11 query tiles (392 -> 467 us per layer).
+struct LptIdx { int bh, rank; };
+__device__ __forceinline__ LptIdx lpt_decode(int idx, int nrank, int G) {
+    const int per = nrank * G;
+    const int grp = idx / per, within = idx - grp * per;
+    LptIdx r;
+    r.rank = within / G;
+    r.bh = grp * G + (within - r.rank * G);
+    return r;
+}
 __device__ __forceinline__ u32x4_t make_rsrc4(const void* p, uint32_t bytes) {
     const uint64_t pa = (uint64_t)p;
     u32x4_t r;
@@ -315,9 +330,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // LPT: 1-D grid, LAST query tile first (under the causal mask it sees the most keys): the launch ends on the short blocks
-    const int nbh = a.B * a.H, nqb = (a.Sq + 127) >> 7;
-    const int b = LPT ? (int)(blockIdx.x % nbh) / a.H : blockIdx.z, hd = LPT ? (int)(blockIdx.x % nbh) % a.H : blockIdx.y;
-    const int q0 = (LPT ? nqb - 1 - (int)(blockIdx.x / nbh) : (int)blockIdx.x) * 128;
+    const int nqb = (a.Sq + 127) >> 7;
+    const LptIdx li = lpt_decode((int)blockIdx.x, nqb, a.lpt_group);
+    const int b = LPT ? li.bh / a.H : blockIdx.z, hd = LPT ? li.bh % a.H : blockIdx.y;
+    const int q0 = (LPT ? nqb - 1 - li.rank : (int)blockIdx.x) * 128;
     const int qi = q0 + wave * 32 + ql;
     const int off = a.Sk - a.Sq;
     const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)(qi < a.Sq ? qi : a.Sq - 1) * a.qs.s;
@@ -777,9 +793,10 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nbh = a.B * a.H, nqb = (a.Sq + 127) >> 7;   // LPT: see flash_fwd2_kernel
-    const int b = LPT ? (int)(blockIdx.x % nbh) / a.H : blockIdx.z, hd = LPT ? (int)(blockIdx.x % nbh) % a.H : blockIdx.y;
-    const int q0 = (LPT ? nqb - 1 - (int)(blockIdx.x / nbh) : (int)blockIdx.x) * 128;
+    const int nqb = (a.Sq + 127) >> 7;   // LPT: see flash_fwd2_kernel
+    const LptIdx li = lpt_decode((int)blockIdx.x, nqb, a.lpt_group);
+    const int b = LPT ? li.bh / a.H : blockIdx.z, hd = LPT ? li.bh % a.H : blockIdx.y;
+    const int q0 = (LPT ? nqb - 1 - li.rank : (int)blockIdx.x) * 128;
     const int qi = q0 + wave * 32 + ql;
     const int qc = qi < a.Sq ? qi : a.Sq - 1;
     const int off = a.Sk - a.Sq;
@@ -908,9 +925,9 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // LPT: 1-D grid walked key block by key block -- under the causal mask key block 0 has the most query tiles, so the longest blocks
     // are dispatched first and the launch ends on the short ones
-    const int nbh = a.B * a.H;
-    const int b = LPT ? (int)(blockIdx.x % nbh) / a.H : blockIdx.z, hd = LPT ? (int)(blockIdx.x % nbh) % a.H : blockIdx.y;
-    const int k0 = (LPT ? (int)(blockIdx.x / nbh) : (int)blockIdx.x) * 128;
+    const LptIdx li = lpt_decode((int)blockIdx.x, (a.Sk + 127) >> 7, a.lpt_group);
+    const int b = LPT ? li.bh / a.H : blockIdx.z, hd = LPT ? li.bh % a.H : blockIdx.y;
+    const int k0 = (LPT ? li.rank : (int)blockIdx.x) * 128;
     const int kw = k0 + wave * 32, kj = kw + ql;
     const int off = a.Sk - a.Sq;
     const int kc = kj < a.Sk ? kj : a.Sk - 1;
@@ -1143,6 +1160,19 @@ int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
     a.qs = st(d->qv); a.ks = st(d->kv); a.vs = st(d->vv); a.os = st(d->ov);
     a.lse = d->lse; a.slopes = d->alibi_slopes; a.kvalid = d->key_valid;
     a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Sk = d->Sk; a.causal = d->causal; a.scale = d->scale;
+    {   // heads per LPT group: the K + V (= Q + dO) panels of a group, Sk x 128 x 2 B x 2 per head, within 64 MB; a divisor of B*H and a
+        // multiple of 8 when there is one (blocks are dealt round-robin to the 8 XCDs: same head -> same XCD), else one group
+        const int64_t nbh = (int64_t)d->B * d->H, per_head = (int64_t)(d->Sk > d->Sq ? d->Sk : d->Sq) * 512;
+        int64_t g = nbh;
+        const int64_t cap = (int64_t(64) << 20) / (per_head > 0 ? per_head : 1);
+        if (g > cap) {
+            g = 0;
+            for (int64_t c = cap - cap % 8; c >= 8; c -= 8)
+                if (nbh % c == 0) { g = c; break; }
+            if (g == 0) g = nbh;
+        }
+        a.lpt_group = (int)g;
+    }
     if (bwd) {
         OTTER_REQUIRE(d->dout && d->delta && d->dq && d->dk && d->dv, "flash bwd: null pointer");
         OTTER_REQUIRE((((uintptr_t)d->dout | (uintptr_t)d->dq | (uintptr_t)d->dk | (uintptr_t)d->dv) & 15) == 0, "flash bwd: 16-byte alignment");
