@@ -222,7 +222,8 @@ typedef struct otter_flash_desc {
 } otter_flash_desc;
 
 int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream);
-/* tuning / A-B hook: 0 = default kernels, 1 = register-staged tiles (v1), 2 = LDS-DMA tiles (v2) */
+/* tuning / A-B hook: 0 = default (LDS-DMA tiles, longest-first block order under the causal mask), 1 = register-staged tiles (v1),
+ * 2 = LDS-DMA tiles on the plain 3-D grid, 3 / 5 = 2 / 0 with dK+dV at two workgroups per CU, 4 = 0 */
 int otter_flash_set_variant(int variant);
 int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream);
 

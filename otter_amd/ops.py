@@ -550,7 +550,8 @@ def set_attn_variant(v: int):
 
 
 def set_flash_variant(v: int):
-    """0 = default, 1 = register-staged tiles, 2 = LDS-DMA tiles (A/B hook of the decoder-host flash attention)."""
+    """0 = default (LDS-DMA tiles, longest-first block order), 1 = register-staged tiles, 2 = LDS-DMA tiles on the plain grid, 3-5 = dK/dV
+    occupancy / order variants (A/B hook of the decoder-host flash attention; csrc/flash.hip)."""
     K.check(K.lib().otter_flash_set_variant(int(v)), "flash_set_variant")
 
 
