@@ -1,4 +1,4 @@
-"""Interleaved A/B rounds of GEMM variants at the gated-FFN shapes (random data).  Usage: gemm_ab.py [rounds]"""
+"""Interleaved A/B rounds of GEMM variants at the gated-FFN shapes (random data).  Usage: gemm_ab.py [rounds] [v1,v2,...]"""
 import json, os, sys, statistics
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,11 +19,18 @@ for (M, N, K) in [(4096, 16384, 4096), (4096, 4096, 16384), (16384, 4096, 4096)]
     B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     res = {}
+    # The slot right after the hipBLASLt leg runs ~15 % slow (the chip comes out of it power-throttled: DESIGN.md 4.3), so the order of
+    # the legs rotates from round to round and every leg is preceded by a throw-away run of the SAME kernel.
+    legs = [("v%d" % v, v) for v in variants] + [("torch", None)]
     for r in range(rounds):
-        for v in variants:
-            ops.set_gemm_variant(v)
-            res.setdefault("v%d" % v, []).append(bench(lambda: ops.gemm_nt(A, B, out=C)))
-        res.setdefault("torch", []).append(bench(lambda: torch.matmul(A, B.t(), out=C)))
+        for name, v in legs[r % len(legs):] + legs[:r % len(legs)]:
+            if v is None:
+                fn = lambda: torch.matmul(A, B.t(), out=C)
+            else:
+                ops.set_gemm_variant(v)
+                fn = lambda: ops.gemm_nt(A, B, out=C)
+            bench(fn)
+            res.setdefault(name, []).append(bench(fn))
     ops.set_gemm_variant(0)
     fl = 2.0 * M * N * K
     print(json.dumps({"shape": [M, N, K], **{k: {"min_us": round(min(v), 1), "med_us": round(statistics.median(v), 1),
