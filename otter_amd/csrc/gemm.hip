@@ -3390,6 +3390,7 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     if (cfg == CFG_T4 || cfg == CFG_T4B || cfg == CFG_T4C || cfg == CFG_T4M) {
         const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;
         unsigned pg = grid.x < 256u ? grid.x : 256u;
+        if (g_order & 0x10) pg = grid.x;   // diagnostics (otter_gemm_set_debug bit 13): one workgroup per tile instead of the persistent grid
 #define LAUNCH_T4(SCH_)                                                                                                    \
     do {                                                                                                                   \
         static bool once = false;                                                                                          \
@@ -3464,7 +3465,7 @@ int otter_gemm_read_timeline(unsigned long long* out, int n) {
 int otter_gemm_set_debug(int flags) {
     g_debug = flags & 255;  // bit 64: tile-phase timeline of variants 18-20 (otter_gemm_read_timeline)
     g_narrow_epilogue = (flags & 256) ? 1 : 0;
-    g_order = (flags >> 9) & 15;  // tile-order override, see tile_of_block
+    g_order = (flags >> 9) & 31;  // tile-order override (bits 9-12, see tile_of_block); bit 13: non-persistent launch of variant 26
     return OTTER_OK;
 }
 

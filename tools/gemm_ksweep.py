@@ -23,11 +23,16 @@ for K in Ks:
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     B = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    for r in range(3):
-        for v in variants:
-            ops.set_gemm_variant(v)
-            res.setdefault(("v%d" % v, K), []).append(bench(lambda: ops.gemm_nt(A, B, out=C)))
-        res.setdefault(("torch", K), []).append(bench(lambda: torch.matmul(A, B.t(), out=C)))
+    legs = [("v%d" % v, v) for v in variants] + [("torch", None)]
+    for r in range(4):   # rotated order + a throw-away run per leg: the slot after a hipBLASLt burst runs slow
+        for name, v in legs[r % len(legs):] + legs[:r % len(legs)]:
+            if v is None:
+                fn = lambda: torch.matmul(A, B.t(), out=C)
+            else:
+                ops.set_gemm_variant(v)
+                fn = lambda: ops.gemm_nt(A, B, out=C)
+            bench(fn)
+            res.setdefault((name, K), []).append(bench(fn))
 ops.set_gemm_variant(0)
 for name in ["v%d" % v for v in variants] + ["torch"]:
     t = [statistics.median(res[(name, K)]) for K in Ks]
