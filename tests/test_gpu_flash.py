@@ -48,6 +48,9 @@ CASES = [
     (1, 2, 130, False, False, None),
     (2, 2, 64, True, False, [64, 1]),
     (1, 4, 321, True, True, [300]),
+    (2, 2, 17, True, True, None),          # a single 32-row query tile (the dK/dV pipeline's prologue-only path)
+    (1, 3, 33, True, False, [33]),         # two query tiles, the second with one row
+    (1, 2, 96, True, True, None),          # three tiles: the 3-slot ring wraps exactly once
 ]
 
 
@@ -153,3 +156,28 @@ def test_mpt_host_flash_matches_sdpa_path(ops, monkeypatch):
     valid = am.bool().cpu().numpy()
     assert relmax(lf[valid], ls[valid]) < 2e-2
     assert relmax(gf, gs) < 3e-2
+
+
+def test_flash_block_order_is_only_an_order(ops):
+    """Longest-first block order, also in GROUPS of heads (B*H = 160 heads x 1024 tokens = 80 MB of K + V > the 64 MB group budget ->
+    groups of 80 heads), against the plain 3-D grid: the same blocks do the same arithmetic, so every output is bit-identical."""
+    from otter_amd.mpt import alibi_slopes
+
+    B, H, S = 2, 80, 1024
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B, S, 3, H, 128, generator=g) * 0.8).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B, S, H, 128, generator=g).to(torch.bfloat16).to(DEV)
+    sl = alibi_slopes(H, 8).float().to(DEV)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    outs = []
+    for variant in (0, 2):
+        ops.set_flash_variant(variant)
+        o, lse = ops.flash_attn_fwd(q, k, v, sl, None, 1.0 / math.sqrt(128), True)
+        d = torch.full_like(qkv, float("nan"))
+        ops.flash_attn_bwd(q, k, v, o, lse, dout, d[:, :, 0], d[:, :, 1], d[:, :, 2], sl, None, 1.0 / math.sqrt(128), True)
+        outs.append((o, lse, d))
+    ops.set_flash_variant(0)
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert not bool(torch.isnan(outs[0][2].float()).any())
