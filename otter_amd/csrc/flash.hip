@@ -984,8 +984,8 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     f32x16_t dk[4], dv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
-    if (qt0 < nqt) issue(qt0, 0);
-    if (qt0 + 1 < nqt) issue(qt0 + 1, 1);
+    issue(qt0, 0);       // unconditional (see the loop): rows past Sq read as zeros
+    issue(qt0 + 1, 1);
     // every load hipcc knows about (the register-resident fragments above) is retired HERE, through the builtin its scoreboard models:
     // otherwise it re-issues its counted waits for them -- down to vmcnt(0) -- in front of the MFMAs of EVERY iteration, and those
     // waits also drain the asm LDS-DMA of the next tile.  (vmcnt(0), expcnt / lgkmcnt untouched: simm16 0x0F70 on gfx9.)
@@ -1012,10 +1012,24 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
             dr[c] = *reinterpret_cast<const bf16x8_t*>(Dn + (qfo ^ (32 * c)));
         }
     }
+    // one DMA piece of tile qt (pieces 0-3: Q / dO halves of this wave's rows; 4-5: the lse / delta words, wave 0 only)
+    auto issue_piece = [&](int qt, int buf, int p) {
+        if (p < 4) {
+            const int i = p >> 1;
+            if (p & 1) dma16_asm(rdo, smem + 24576 + buf * 8192 + (wave * 2 + i) * 1024, vd[i], (uint32_t)qt * 32u * dorow);
+            else dma16_asm(rq, smem + buf * 8192 + (wave * 2 + i) * 1024, vq[i], (uint32_t)qt * 32u * qrow);
+        } else {
+            if (p == 4) dma4_asm(rls, stat + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
+            else dma4_asm(rdl, stat + 768 + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
+        }
+    };
+    // dK / dV MFMAs through asm with AGPR accumulators ("+a"); s_nop 1 covers a VALU-written (cvt_pk) B operand; the _MEM form also orders
+    // the statement against the compiler's LDS reads (phase 3 places two row-fragment reads behind every MFMA)
+#define MFMA_ACC(ACC_, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_))
+#define MFMA_ACC_MEM(ACC_, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
     int cur = 0;
     for (int qt = qt0; qt < nqt; ++qt, cur = cur == 2 ? 0 : cur + 1) {
         DSTAMP(1 + 5 * (qt - qt0));
-        DSTAMP(2 + 5 * (qt - qt0));
         const int i0 = qt * 32;
         // (no per-wave skip of tiles that precede the wave's keys: the branch makes hipcc shuttle the 128 accumulator
         //  registers between VGPRs and AGPRs on every iteration, which costs more than the <= 3 masked tiles it saves)
@@ -1023,115 +1037,164 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         const char* Dc = smem + 24576 + cur * 8192;
         const float* lse_s = reinterpret_cast<const float*>(stat + cur * 256);
         const float* dl_s = reinterpret_cast<const float*>(stat + 768 + cur * 256);
-        // All LDS reads of the tile are issued up front (48 per wave: 16 row fragments for S / dP, 32 transpose reads for dV / dK; 128
-        // registers of fragments -- one wave per SIMD has them): the timeline (tools/flash_timeline_dkv.py) showed the MFMAs of both
-        // phases waiting on ds_read latency one fragment at a time (3 900 cycles per tile against 1 024 of MFMA work).
+        // The DMA of tile qt+2, the mid-iteration wait + barrier and the row-fragment reads of tile qt+1 are UNCONDITIONAL: past the last
+        // tile the source rows lie beyond the descriptor's range (the DMA writes zeros into a dead slot) and the fragments read are never
+        // used.  Guarding each piece / read on qt+2 < nqt cost 19 scalar branches + ~40 scalar ALU instructions per iteration, and with one
+        // wave per SIMD every instruction, scalar or not, is an issue slot of four cycles.
+        const int nb = cur == 0 ? 2 : cur - 1;   // slot of tile qt-1 = slot of tile qt+2
+        // ---- phase 1: S^T / dP^T (16 MFMAs, VGPR accumulators through asm: see below).  Every MFMA pair is followed by its share of the
+        // other work of the iteration -- two transpose-read fragments of THIS tile (needed in phase 3) and one DMA piece of tile qt+2 --
+        // and a sched_barrier pins that order: one wave per SIMD issues in order, so anything issued in a burst (48 LDS reads, 4-6 DMA
+        // pieces of ~80 cycles each) leaves the matrix pipe idle for its whole issue time (tools/flash_timeline_dkv.py: 1 260 cycles for
+        // this phase against 512 of MFMA work when reads and DMA came first / in the middle).
+        // S^T and dP^T accumulate in VGPRs: with the builtin hipcc puts them in a[0:31], which hold a quarter of the dK / dV accumulators,
+        // and moves those 32 registers out to VGPRs and back around them on every tile (96 v_accvgpr_* per iteration).  Hazards the
+        // assembler does not pad: 18+ wait states after the last MFMA before VALU reads (the operands come from LDS reads the compiler waits
+        // for and from long-lived registers: no VALU-write -> MFMA-read hazard here).
         bf16x8_t tD[2][4], tQ[2][4];
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                tD[c][db] = tr_pi_frag(Dc, to1, to2, db, 16 * c);
-                tQ[c][db] = tr_pi_frag(Qc, to1, to2, db, 16 * c);
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        // S^T and dP^T accumulate in VGPRs through asm MFMAs: with the builtin hipcc puts them in a[0:31], which hold a quarter of the
-        // dK / dV accumulators, and moves those 32 registers out to VGPRs and back around them on every tile (96 v_accvgpr_* per
-        // iteration; the softmax would read s / dp out of AGPRs one by one as well).  Hazards the assembler does not pad: a leading
-        // s_nop 1 (VALU / LDS-written operand -> MFMA), and 18 wait states after the last MFMA before the softmax reads the results.
         f32x16_t s, dp;
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(qr[0]), "v"(kf[0]));
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dp) : "v"(dr[0]), "v"(vf[0]));
 #pragma unroll
-        for (int c = 1; c < 8; ++c) {
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(qr[c]), "v"(kf[c]));
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dp) : "v"(dr[c]), "v"(vf[c]));
-            // the DMA of tile qt+2 (into the slot of tile qt-1, which every wave left before the barrier above) is issued while the matrix
-            // pipe works through the queue: an LDS-DMA piece costs ~80 cycles of issue that would otherwise sit between two phases
-            if (c == 3 && qt + 2 < nqt) issue(qt + 2, cur == 0 ? 2 : cur - 1);
+        for (int c = 0; c < 8; ++c) {
+            if (c == 0) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(qr[0]), "v"(kf[0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dp) : "v"(dr[0]), "v"(vf[0]));
+            } else {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(qr[c]), "v"(kf[c]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dp) : "v"(dr[c]), "v"(vf[c]));
+            }
+            {   // fragments 2c, 2c+1 of the list  tD[0][0..3], tQ[0][0..3], tD[1][0..3], tQ[1][0..3]
+                const int cc = c >> 2, db0 = (c & 1) * 2;
+                if (((c >> 1) & 1) == 0) {
+                    tD[cc][db0] = tr_pi_frag(Dc, to1, to2, db0, 16 * cc);
+                    tD[cc][db0 + 1] = tr_pi_frag(Dc, to1, to2, db0 + 1, 16 * cc);
+                } else {
+                    tQ[cc][db0] = tr_pi_frag(Qc, to1, to2, db0, 16 * cc);
+                    tQ[cc][db0 + 1] = tr_pi_frag(Qc, to1, to2, db0 + 1, 16 * cc);
+                }
+            }
+            if (c < 4) issue_piece(qt + 2, nb, c);
+            else if (c == 4 && wave == 0) { issue_piece(qt + 2, nb, 4); issue_piece(qt + 2, nb, 5); }
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s), "+v"(dp));
-        DSTAMP(3 + 5 * (qt - qt0));
-        // Visibility of query row i0 + idx (idx = 8g + 4h2 + e) for this lane's key: lo <= idx < hi.  One unsigned compare and one
-        // v_cndmask per element, no control flow: the short-circuit form `kok && (interior || (i < Sq && (!causal || kj <= i + off)))`
-        // compiled into 29 EXEC-mask branches per iteration, which also kept the scheduler from moving anything across them.
-        // Interior tiles (every row below Sq and at or past the wave's last key; no key-padding mask) skip the mask arithmetic.
+        DSTAMP(2 + 5 * (qt - qt0));
+        // ---- phase 2: softmax of rows 0-7 (element r = 4g + e is query row i0 + 8g + 4h2 + e), then rows 8-15 one element per dV / dK
+        // MFMA of the first half (c = 0), then the second half's MFMAs with the row-fragment reads of tile qt+1 between them.
+        // Visibility of a row for this lane's key: lo <= idx < hi, one unsigned compare + v_cndmask (the short-circuit form compiled into
+        // 29 EXEC-mask branches per iteration); interior tiles without a key-padding mask skip the mask arithmetic.
         const bool interior = i0 + 31 < a.Sq && (!a.causal || kw + 31 <= i0 + off);  // wave-uniform
-        if (interior && a.kvalid == nullptr) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
-                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, bias2 - lv[e]));
-                    s[r] = p;
-                    dp[r] = p * (dp[r] - dvv[e]);
-                }
-            }
-        } else {
-            int lo = 0, hi = 32;
-            if (!interior) {
-                const int vis = a.causal ? kj - off - i0 : 0;     // first visible row, relative to the tile
-                lo = vis > 0 ? vis : 0;
-                hi = a.Sq - i0 < 32 ? a.Sq - i0 : 32;
-            }
-            if (!kok) hi = 0;
-            const unsigned span = hi > lo ? (unsigned)(hi - lo) : 0u;
-            const int idx0 = 4 * h2 - lo;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
-                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
-                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const bool ok = (unsigned)(idx0 + 8 * g + e) < span;
-                    const float pe = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, bias2 - lv[e]));
-                    const float p = ok ? pe : 0.f;
-                    s[r] = p;
-                    dp[r] = p * (dp[r] - dvv[e]);
-                }
-            }
+        int lo = 0, hi = 32;
+        if (!interior) {
+            const int vis = a.causal ? kj - off - i0 : 0;     // first visible row, relative to the tile
+            lo = vis > 0 ? vis : 0;
+            hi = a.Sq - i0 < 32 ? a.Sq - i0 : 32;
         }
-#ifdef OTTER_FLASH_TIMING
-        asm volatile("" :: "v"(s[15]), "v"(dp[15]));
-#endif
+        if (!kok) hi = 0;
+        const unsigned span = hi > lo ? (unsigned)(hi - lo) : 0u;
+        const int idx0 = 4 * h2 - lo;
+        // (macro, not a lambda: s[r] / dp[r] must stay register indices)
+#define DKV_ELEM(R_, FAST_, LV_, DV_)                                                                  \
+    do {                                                                                               \
+        const float pe_ = __builtin_amdgcn_exp2f(fmaf(s[R_], sc2, bias2 - (LV_)));                      \
+        const bool ok_ = (FAST_) || (unsigned)(idx0 + 8 * ((R_) >> 2) + ((R_) & 3)) < span;            \
+        const float p_ = ok_ ? pe_ : 0.f;                                                              \
+        s[R_] = p_;                                                                                    \
+        dp[R_] = p_ * (dp[R_] - (DV_));                                                                \
+    } while (0)
+        {
+            float lv[8], dvv[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * g + 4 * h2);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * g + 4 * h2);
+                lv[4 * g] = l4.x; lv[4 * g + 1] = l4.y; lv[4 * g + 2] = l4.z; lv[4 * g + 3] = l4.w;
+                dvv[4 * g] = d4.x; dvv[4 * g + 1] = d4.y; dvv[4 * g + 2] = d4.z; dvv[4 * g + 3] = d4.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) DKV_ELEM(r, false, lv[r], dvv[r]);
+        }
+        const bf16x8_t pf0 = pack8(s, 0), dsf0 = pack8(dp, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DSTAMP(3 + 5 * (qt - qt0));
+        {
+            float lv[8], dvv[8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 8 * (g + 2) + 4 * h2);
+                const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 8 * (g + 2) + 4 * h2);
+                lv[4 * g] = l4.x; lv[4 * g + 1] = l4.y; lv[4 * g + 2] = l4.z; lv[4 * g + 3] = l4.w;
+                dvv[4 * g] = d4.x; dvv[4 * g + 1] = d4.y; dvv[4 * g + 2] = d4.z; dvv[4 * g + 3] = d4.w;
+            }
+            // (one code path: a wave-uniform `interior` branch around these MFMAs made hipcc carry the 128 dK / dV accumulators through
+            //  both arms -- 128 AGPR copies + 168 B of scratch per lane, whose reloads are VMEM loads that drain the DMA; an interior tile
+            //  simply has lo = 0, hi = 32)
+            // Rows 8-15 in two groups of four, each stage of a group (argument, exp2, mask, dS) behind one dV / dK MFMA.  Everything is pinned:
+            // the MFMAs are asm (the builtin is pure to the IR optimiser, which gathered all eight in front of the softmax whatever the
+            // source order and the sched_barriers said), and an empty asm re-defines a stage's four results before the next MFMA, so a
+            // stage can neither rise above the previous MFMA nor sink below the next.  Four independent elements per stage: one element
+            // per MFMA (first attempt) serialised each element's dependent chain -- 125 cycles per pair instead of ~60.
+#define DKV_MFMA0(I_)                                                              \
+    do {                                                                           \
+        if ((I_) & 1) MFMA_ACC(dk[(I_) >> 1], tQ[0][(I_) >> 1], dsf0);             \
+        else MFMA_ACC(dv[(I_) >> 1], tD[0][(I_) >> 1], pf0);                       \
+    } while (0)
+#pragma unroll
+            for (int grp = 0; grp < 2; ++grp) {
+                const int r0 = 8 + 4 * grp;
+                float t0, t1, t2, t3;
+                asm volatile("" : "+v"(s), "+v"(dp));
+                DKV_MFMA0(4 * grp + 0);
+                t0 = fmaf(s[r0 + 0], sc2, bias2 - lv[4 * grp + 0]);
+                t1 = fmaf(s[r0 + 1], sc2, bias2 - lv[4 * grp + 1]);
+                t2 = fmaf(s[r0 + 2], sc2, bias2 - lv[4 * grp + 2]);
+                t3 = fmaf(s[r0 + 3], sc2, bias2 - lv[4 * grp + 3]);
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                DKV_MFMA0(4 * grp + 1);
+                t0 = __builtin_amdgcn_exp2f(t0); t1 = __builtin_amdgcn_exp2f(t1); t2 = __builtin_amdgcn_exp2f(t2); t3 = __builtin_amdgcn_exp2f(t3);
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                DKV_MFMA0(4 * grp + 2);
+                t0 = (unsigned)(idx0 + 8 * ((r0 + 0) >> 2) + ((r0 + 0) & 3)) < span ? t0 : 0.f;
+                t1 = (unsigned)(idx0 + 8 * ((r0 + 1) >> 2) + ((r0 + 1) & 3)) < span ? t1 : 0.f;
+                t2 = (unsigned)(idx0 + 8 * ((r0 + 2) >> 2) + ((r0 + 2) & 3)) < span ? t2 : 0.f;
+                t3 = (unsigned)(idx0 + 8 * ((r0 + 3) >> 2) + ((r0 + 3) & 3)) < span ? t3 : 0.f;
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                DKV_MFMA0(4 * grp + 3);
+                s[r0 + 0] = t0; s[r0 + 1] = t1; s[r0 + 2] = t2; s[r0 + 3] = t3;
+                dp[r0 + 0] = t0 * (dp[r0 + 0] - dvv[4 * grp + 0]);
+                dp[r0 + 1] = t1 * (dp[r0 + 1] - dvv[4 * grp + 1]);
+                dp[r0 + 2] = t2 * (dp[r0 + 2] - dvv[4 * grp + 2]);
+                dp[r0 + 3] = t3 * (dp[r0 + 3] - dvv[4 * grp + 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#undef DKV_MFMA0
+        }
+#undef DKV_ELEM
+        const bf16x8_t pf1 = pack8(s, 8), dsf1 = pack8(dp, 8);
         DSTAMP(4 + 5 * (qt - qt0));
-        if (qt + 1 < nqt) {
-            // tile qt+1 has landed when at most the pieces of tile qt+2 are outstanding (wave 0 also carries the two statistics pieces);
-            // lgkmcnt(0): this wave's LDS reads of tile qt (transpose reads, lse / delta) have returned, so after the barrier its slot is dead
-            if (qt + 2 < nqt) {
-                if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const int nx = cur == 2 ? 0 : cur + 1;
-            const char* Qn = smem + nx * 8192;
-            const char* Dn = smem + 24576 + nx * 8192;
+        // tile qt+1 has landed when at most the pieces of tile qt+2 are outstanding (wave 0 also carries the two statistics pieces);
+        // lgkmcnt(0): this wave's LDS reads of tile qt (transpose reads, lse / delta) have returned, so after the barrier its slot is dead
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- phase 3: dV / dK MFMAs of the second half, the 16 row-fragment reads of tile qt+1 (for the NEXT iteration's phase 1) two per MFMA
+        const int nx = cur == 2 ? 0 : cur + 1;
+        const char* Qn = smem + nx * 8192;
+        const char* Dn = smem + 24576 + nx * 8192;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                qr[c] = *reinterpret_cast<const bf16x8_t*>(Qn + (qfo ^ (32 * c)));
-                dr[c] = *reinterpret_cast<const bf16x8_t*>(Dn + (qfo ^ (32 * c)));
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const bf16x8_t pf = pack8(s, 8 * c), dsf = pack8(dp, 8 * c);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tD[c][db], pf, dv[db], 0, 0, 0);
-                dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tQ[c][db], dsf, dk[db], 0, 0, 0);
-            }
+        for (int i = 0; i < 8; ++i) {
+            if (i & 1) MFMA_ACC_MEM(dk[i >> 1], tQ[1][i >> 1], dsf1);
+            else MFMA_ACC_MEM(dv[i >> 1], tD[1][i >> 1], pf1);
+            qr[i] = *reinterpret_cast<const bf16x8_t*>(Qn + (qfo ^ (32 * i)));
+            dr[i] = *reinterpret_cast<const bf16x8_t*>(Dn + (qfo ^ (32 * i)));
+            __builtin_amdgcn_sched_barrier(0);
         }
         DSTAMP(5 + 5 * (qt - qt0));
     }
+#undef MFMA_ACC
+#undef MFMA_ACC_MEM
+    // the accumulators were last written by asm MFMAs hipcc knows nothing about: 18+ wait states before it reads them out of the AGPRs
+    asm volatile("s_nop 15\n\ts_nop 3" : "+a"(dk[0]), "+a"(dk[1]), "+a"(dk[2]), "+a"(dk[3]), "+a"(dv[0]), "+a"(dv[1]), "+a"(dv[2]), "+a"(dv[3]));
     DSTAMP(90);
     if (kj < a.Sk) {
         store_dt(a.dk + b * a.dks.b + hd * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, h2);

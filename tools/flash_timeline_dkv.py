@@ -27,8 +27,8 @@ rel = lambda i: t[i] - t[0]
 rows = []
 for it in range(16):
     b = 1 + 5 * it
-    rows.append({"it": it, "top": rel(b), "wait+barrier": t[b + 1] - t[b], "reads+S,dP+dma": t[b + 2] - t[b + 1], "softmax": t[b + 3] - t[b + 2],
-                 "dV,dK": t[b + 4] - t[b + 3]})
+    rows.append({"it": it, "top": rel(b), "S,dP+reads+dma": t[b + 1] - t[b], "softmax A": t[b + 2] - t[b + 1], "dV,dK(0)+softmax B": t[b + 3] - t[b + 2],
+                 "barrier+dV,dK(1)+row reads": t[b + 4] - t[b + 3]})
 print(json.dumps({"prologue_to_loop": rel(1), "loop_end": rel(90), "stores_done": rel(91)}))
 for r in rows:
     print(json.dumps(r))
