@@ -231,3 +231,18 @@ def test_product_never_imports_the_oracle():
         uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and ("oracle" in ((getattr(n, "module", None) or "") + " ".join(a.name for a in n.names)))
                    for n in ast.walk(fn))
         assert (not uses) or fn.name == "cpu_baseline", fn.name
+
+
+def test_mpt_mlp_cpu_path_is_the_reference_gelu():
+    """The decoder MLP (mpt/blocks.py:37-49) off the GPU: `functional.gelu` falls back to torch's exact-erf GELU and `MPTMLP.forward`
+    takes the nn.GELU() branch, so CPU parity runs see the reference's arithmetic (the HIP kernels only ever take CUDA tensors)."""
+    import torch
+    from otter_amd import functional as OF
+    from otter_amd.mpt import MPTMLP
+
+    torch.manual_seed(3)
+    x = torch.randn(5, 16)
+    assert torch.equal(OF.gelu(x), torch.nn.functional.gelu(x))
+    mlp = MPTMLP(16, 4, bias=False)
+    ref = mlp.down_proj(torch.nn.functional.gelu(mlp.up_proj(x)))
+    assert torch.equal(mlp(x), ref)
