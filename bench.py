@@ -185,9 +185,10 @@ def synth_batch(model, B, T, device, seed, frames=1):
     ids[:, 1] = model.media_token_id
     ids[:, T // 4] = answer_id
     ids[:, T - 1] = model.eoc_token_id
-    labels = masking(ids, answer_id, model.eoc_token_id, 0)
     mask = torch.ones(B, T, dtype=torch.long)
-    return vision_x, ids.to(device), mask.to(device), labels.to(device)
+    ids, mask = ids.to(device), mask.to(device)
+    tok_ids = (answer_id, model.eoc_token_id, 0)        # <answer>, <|endofchunk|>, eos: what the reference's masking() keys on
+    return vision_x, ids, mask, masking(ids, *tok_ids), tok_ids
 
 
 def cpu_baseline(T=512):
@@ -318,12 +319,23 @@ def main():
     ap.add_argument("--debug-layers", type=int, default=0, help="DEBUG ONLY: shrink MPT to this many layers (not a valid bench)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the ranks ourselves (one process per GPU), exactly the launch the driver uses
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("OTTER_FORCE_DIST") == "1"  # the env switch exercises the RCCL path on one GPU
@@ -349,7 +361,14 @@ def main():
     step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16,
                      force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1")
     B, T = args.batch, args.seq
-    batch = synth_batch(model, B, T, device, seed=1000 + rank, frames=8 if args.config == "c4" else 1)
+    from otter_amd.train import masking
+
+    vision_x, ids, amask, labels0, tok_ids = synth_batch(model, B, T, device, seed=1000 + rank, frames=8 if args.config == "c4" else 1)
+    batch = (vision_x, ids, amask, labels0)
+
+    def one_step():
+        # the reference builds the labels inside its step (instruction_following.py:163-192): same here, on the device, no host sync
+        return step(vision_x, ids, amask, masking(ids, *tok_ids))
 
     def sync():
         torch.cuda.synchronize()
@@ -359,13 +378,13 @@ def main():
 
     loss = None
     for _ in range(args.warmup):
-        loss = step(*batch)
+        loss = one_step()
     M, N, Kd = B * T, 16384, 4096
     ops.prof_arm_gemm(M, N, Kd, max_events=max(64, args.steps * 8 * 3 + 8))
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step(*batch)
+        loss = one_step()
     sync()
     elapsed = time.perf_counter() - t0
     n_launch, gemm_ms = ops.prof_collect()

@@ -42,11 +42,16 @@ class GradReducer:
     """Bucketed, overlapped gradient averaging across the data-parallel group."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 640 << 20,
-                 process_group: Optional[dist.ProcessGroup] = None, grad_dtype: torch.dtype = torch.float32, force: bool = False):
+                 process_group: Optional[dist.ProcessGroup] = None, grad_dtype: torch.dtype = torch.float32, force: bool = False,
+                 row_only: Optional[dict] = None):
+        """row_only: {parameter: row} -- parameters whose gradient is known to be zero outside ONE row when wait() is called
+        (the reference's `--mask_lm_head`, train.mask_embedding): they stay out of the buckets, keep an ordinary .grad, and only
+        that row is averaged across ranks."""
         self.group = process_group
+        self.row_only = dict(row_only or {})
         self.force = force  # run the collectives even with one rank (exercises the RCCL path on a single GPU)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        ps = [p for p in params if p.requires_grad]
+        ps = [p for p in params if p.requires_grad and p not in self.row_only]
         if not ps:
             raise ValueError("GradReducer: no trainable parameters")
         # reverse registration order ~ the order gradients become ready in backward
@@ -93,6 +98,8 @@ class GradReducer:
             b.work = None
             for p in b.params:
                 p.grad = None
+        for p in self.row_only:
+            p.grad = None
 
     # ---- grad sink protocol (otter_amd.functional._wgrad) ----
     def take(self, p: torch.nn.Parameter):
@@ -151,13 +158,44 @@ class GradReducer:
             for b in self.buckets:
                 if b.work is None:
                     self._launch(b)
+            rows = self._launch_rows()
             for b in self.buckets:
                 b.work.wait()
                 if getattr(b, "_needs_div", False):
                     b.flat.div_(self.world)
                     b._needs_div = False
+            self._finish_rows(rows)
         for b in self.buckets:
             b.ready.clear()
+
+    def _launch_rows(self):
+        """One small collective for all row-only parameters (every rank holds the same parameter set in the same order)."""
+        if not self.row_only:
+            return None
+        items = list(self.row_only.items())
+        parts = []
+        for p, r in items:
+            g = p.grad
+            parts.append(g[r].reshape(-1).to(torch.float32) if g is not None else torch.zeros(p.shape[1:].numel(), dtype=torch.float32, device=p.device))
+        flat = torch.cat(parts)
+        avg = dist.get_backend(self.group) == "nccl"
+        work = dist.all_reduce(flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return items, flat, work, avg
+
+    def _finish_rows(self, rows):
+        if rows is None:
+            return
+        items, flat, work, avg = rows
+        work.wait()
+        if not avg:
+            flat.div_(self.world)
+        off = 0
+        for p, r in items:
+            n = p.shape[1:].numel()
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            p.grad[r] = flat[off:off + n].view(p.shape[1:]).to(p.grad.dtype)
+            off += n
 
     def close(self):
         """Detach from autograd and from the weight-gradient GEMMs (the parameters keep their current .grad views)."""

@@ -2,6 +2,10 @@
 bench.py and the tests can drive one step without the reference's dataset / accelerate / wandb stack:
 
   masking()            label construction                        instruction_following.py:163-192
+  find_and_remove_tokens  --remove_answer_token / --remove_eos_token   pipeline/train/train_utils.py:276-305
+  mask_embedding       --mask_lm_head                            instruction_following.py:228-244
+  get_checkpoint / save_checkpoint / save_final_weights / load_trained_ckpt
+                       trainable-only checkpoints                 train_utils.py:60-67,183-221,234-262; instruction_following.py:438-442
   get_grouped_params   weight-decay grouping by parameter name    pipeline/train/train_utils.py:167-183
   TrainStep            forward (bf16 autocast) -> backward -> DP gradient average -> clip_grad_norm_(1.0) -> AdamW
                                                                   instruction_following.py:200-251
@@ -19,27 +23,138 @@ from .dp import GradReducer
 def masking(input_ids: torch.Tensor, answer_token_id: int, endofchunk_token_id: int, eos_token_id: int,
             masking_number: int = -100) -> torch.Tensor:
     """Labels = input ids on every <answer> ... <|endofchunk|> span (answer token excluded, endofchunk included), eos tokens
-    kept, everything else -100, column 0 always -100.  Same result as the reference's per-sample Python loop, computed
-    per row with tensor ops (the pairing rule -- each <answer> matched with the first later unused <|endofchunk|> -- is
-    kept by walking the (few) answer positions of a row)."""
+    kept, everything else -100, column 0 always -100: the result of the reference's per-sample Python loop
+    (instruction_following.py:163-192), computed for the whole batch with scans -- no `.tolist()` / `.item()`, so on the GPU
+    it costs no host synchronisation and can sit inside the timed step like the reference's own call.
+
+    First pass of the reference (`j` pointer): each <answer>, in order, takes the first not-yet-used <|endofchunk|> after it.
+    That is a FIFO queue of pending answers: q(t+1) = max(q(t) + [answer at t] - [endofchunk at t], 0), an endofchunk is
+    consumed iff q > 0 when it arrives.  With S = cumsum(answer - endofchunk), q(t) = S(t-1) - min(0, min_{s<t} S(s)) (the
+    Lindley recursion), and a token lies inside some matched span iff  min(#answers before t, m) > #consumed endofchunks
+    before t  (m = consumed endofchunks of the row: the first m answers are the matched ones).
+    Second pass (`zip(answers, endofchunks)`, :184-185): k-th answer with k-th endofchunk, spans (a_k, e_k] (empty when
+    e_k < a_k): evaluated densely over the sorted positions ([B, T, T] booleans)."""
     B, T = input_ids.shape
+    dev = input_ids.device
+    ans = input_ids == answer_token_id
+    eoc = input_ids == endofchunk_token_id
+    a_i, e_i = ans.to(torch.int64), eoc.to(torch.int64)
+    # ---- first pass: FIFO matching through the queue length ----
+    S = torch.cumsum(a_i - e_i, dim=1)                                   # S(t): after processing position t
+    S_prev = torch.cat([torch.zeros(B, 1, dtype=torch.int64, device=dev), S[:, :-1]], dim=1)
+    low = torch.clamp(torch.cummin(S_prev, dim=1).values, max=0)         # min(0, min_{s <= t-1} S(s)); S(-1) = 0
+    q = S_prev - low                                                     # pending answers when position t is processed
+    consumed = eoc & (q > 0)
+    c_i = consumed.to(torch.int64)
+    a_before = torch.cumsum(a_i, dim=1) - a_i                            # strictly before t
+    c_before = torch.cumsum(c_i, dim=1) - c_i
+    m = c_i.sum(dim=1, keepdim=True)
+    span1 = torch.minimum(a_before, m) > c_before
+    # ---- second pass: positional zip of the sorted answer / endofchunk positions ----
+    pos = torch.arange(T, device=dev).expand(B, T)
+    a_pos = torch.sort(torch.where(ans, pos, torch.full_like(pos, T)), dim=1).values          # padded with T  -> a < t never
+    e_pos = torch.sort(torch.where(eoc, pos, torch.full_like(pos, 2 * T)), dim=1).values
+    e_pos = torch.where(e_pos >= 2 * T, torch.full_like(e_pos, -1), e_pos)                    # padded with -1 -> t <= e never
+    t3 = pos[:, None, :]
+    span2 = ((a_pos[:, :, None] < t3) & (t3 <= e_pos[:, :, None])).any(dim=1)
     labels = torch.where(input_ids == eos_token_id, input_ids, torch.full_like(input_ids, masking_number))
-    for i in range(B):
-        row = input_ids[i]
-        ans = torch.nonzero(row == answer_token_id, as_tuple=False).flatten().tolist()
-        eoc = torch.nonzero(row == endofchunk_token_id, as_tuple=False).flatten().tolist()
-        j = 0
-        for a in ans:
-            while j < len(eoc) and eoc[j] < a:
-                j += 1
-            if j < len(eoc):
-                e = eoc[j]
-                labels[i, a + 1:e + 1] = row[a + 1:e + 1]
-                j += 1
-        for a, e in zip(ans, eoc):  # the reference's second (positional zip) pass, instruction_following.py:184-185
-            labels[i, a + 1:e + 1] = row[a + 1:e + 1]
+    labels = torch.where(span1 | span2, input_ids, labels)
     labels[:, 0] = masking_number
     return labels
+
+
+def find_and_remove_tokens(input_ids: torch.Tensor, labels: torch.Tensor, attention_mask: torch.Tensor, token_id: int,
+                           pad_token_id: int):
+    """pipeline/train/train_utils.py:276-305: drop every `token_id` position from the three tensors (per row), right-pad the
+    shortened rows to the longest one with (pad_token_id, -100, 0).  One stable sort + gather for the whole batch; the only
+    host synchronisation is the new width (the reference's `pad_sequence` has the same one)."""
+    B, T = input_ids.shape
+    keep = input_ids != token_id
+    n_keep = keep.sum(dim=1)
+    width = int(n_keep.max().item()) if B > 0 else 0
+    # stable sort on "dropped" flags keeps the surviving tokens in order at the front of each row
+    order = torch.sort((~keep).to(torch.int8), dim=1, stable=True).indices[:, :width]
+    valid = torch.arange(width, device=input_ids.device)[None, :] < n_keep[:, None]
+    new_ids = torch.where(valid, input_ids.gather(1, order), torch.full_like(order, pad_token_id))
+    new_labels = torch.where(valid, labels.gather(1, order), torch.full_like(order, -100))
+    new_mask = torch.where(valid, attention_mask.gather(1, order), torch.zeros_like(order).to(attention_mask.dtype))
+    return new_ids, new_labels, new_mask
+
+
+def mask_embedding(embedding: torch.nn.Module, keep_row: int) -> None:
+    """instruction_following.py:228-244 (`--mask_lm_head`): keep only the <answer> row of the embedding gradient (the
+    reference multiplies by a one-row mask; here the other rows are zeroed in place -- no 826 MB mask tensor)."""
+    w = embedding.weight
+    if not w.requires_grad or w.grad is None:
+        return
+    g = w.grad
+    row = g[keep_row].clone()
+    g.zero_()
+    g[keep_row] = row
+
+
+def get_checkpoint(model: torch.nn.Module) -> dict:
+    """pipeline/train/train_utils.py:60-67: the state dict without the frozen parameters (buffers stay, as in the reference)."""
+    sd = model.state_dict()
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            sd.pop(name, None)
+    return sd
+
+
+def save_checkpoint(model, save_dir: str, epoch: Optional[int] = None, global_step: Optional[int] = None, is_main_process: bool = True,
+                    delete_previous: bool = False, save_steps_interval: int = -1) -> str:
+    """train_utils.py:183-221: `checkpoint_steps_{step}.pt` = {"steps", "model_state_dict"} or `checkpoint_{epoch}.pt` =
+    {"model_state_dict"} (trainable parameters only) + the model's config.json, written by the main process."""
+    if global_step:
+        path = os.path.join(save_dir, "checkpoint_steps_%d.pt" % global_step)
+        payload = {"steps": global_step, "model_state_dict": get_checkpoint(model)}
+    else:
+        path = os.path.join(save_dir, "checkpoint_%d.pt" % (epoch or 0))
+        payload = {"model_state_dict": get_checkpoint(model)}
+    if is_main_process:
+        os.makedirs(save_dir, exist_ok=True)
+        torch.save(payload, path)
+        model.config.save_pretrained(save_dir)
+        if delete_previous:
+            prev = None
+            if global_step and save_steps_interval > 0:
+                # (the reference looks for `checkpoint_step_...` here -- a typo that never matches what it wrote; the intent is kept)
+                prev = os.path.join(save_dir, "checkpoint_steps_%d.pt" % (global_step - save_steps_interval))
+            elif not global_step and epoch:
+                prev = os.path.join(save_dir, "checkpoint_%d.pt" % (epoch - 1))
+            if prev and os.path.exists(prev):
+                os.remove(prev)
+    return path
+
+
+def save_final_weights(model, save_dir: str, is_main_process: bool = True, save_hf_model: bool = False) -> str:
+    """train_utils.py:234-262: config.json + `final_weights.pt` (trainable parameters only), or the whole model in the HF layout."""
+    if is_main_process:
+        os.makedirs(save_dir, exist_ok=True)
+        model.config.save_pretrained(save_dir)
+        if save_hf_model:
+            model.save_pretrained(save_dir, safe_serialization=False)
+        else:
+            torch.save(get_checkpoint(model), os.path.join(save_dir, "final_weights.pt"))
+    return os.path.join(save_dir, "final_weights.pt")
+
+
+def load_trained_ckpt(model, path: str):
+    """instruction_following.py:438-442: `--trained_ckpt`; accepts final_weights.pt and checkpoint_*.pt ("model_state_dict").
+    Loads non-strictly like the reference, but a key the model does not have is an error, and so is a trainable parameter the
+    checkpoint does not cover (the reference silently keeps its random init)."""
+    ckpt = torch.load(path, map_location="cpu")
+    if isinstance(ckpt, dict) and "model_state_dict" in ckpt:
+        ckpt = ckpt["model_state_dict"]
+    res = model.load_state_dict(ckpt, strict=False)
+    if res.unexpected_keys:
+        raise KeyError("checkpoint has keys the model does not: %s" % res.unexpected_keys[:5])
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    lost = sorted(trainable.intersection(res.missing_keys))
+    if lost:
+        raise KeyError("checkpoint does not cover trainable parameters: %s" % lost[:5])
+    return res
 
 
 def get_grouped_params(model: torch.nn.Module, wd: float):
@@ -53,12 +168,29 @@ def get_grouped_params(model: torch.nn.Module, wd: float):
     return [{"params": with_wd, "weight_decay": wd}, {"params": without_wd, "weight_decay": 0.0}]
 
 
+def _lm_head_modules(model):
+    """The modules `--mask_lm_head` touches, keyed on the language model's class name exactly like the reference
+    (instruction_following.py:238-244)."""
+    lm = model.lang_encoder
+    name = lm.__class__.__name__
+    if name in ("MPTForCausalLM", "MosaicGPT"):
+        return [lm.transformer.wte]
+    if "LlamaForCausalLM" in name:
+        return [lm.model.embed_tokens, lm.lm_head]
+    raise NotImplementedError("mask_lm_head: unknown language model class %s" % name)
+
+
 class TrainStep:
     """One optimizer step of the Otter instruction-following recipe on this rank's micro-batch."""
 
     def __init__(self, model, lr: float = 1e-5, weight_decay: float = 0.1, max_grad_norm: float = 1.0,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, process_group=None, bucket_bytes: int = 640 << 20,
-                 fused_optimizer: bool = True, force_reducer: bool = False, hip_optimizer: Optional[bool] = None):
+                 fused_optimizer: bool = True, force_reducer: bool = False, hip_optimizer: Optional[bool] = None,
+                 mask_lm_head: bool = False, answer_token_id: Optional[int] = None):
+        """mask_lm_head + answer_token_id: the reference's `--mask_lm_head` (instruction_following.py:228-244): only the <answer>
+        row of the input (MPT: tied) embedding gradient -- and of lm_head for a LLaMA host -- survives.  Masking commutes with the
+        DP average, so with a reducer those tensors leave the flat buckets and ONE ROW each is all-reduced (16 KB instead of
+        826 MB for OTTER-MPT7B)."""
         self.model = model
         self.max_grad_norm = max_grad_norm
         self.autocast_dtype = autocast_dtype
@@ -77,8 +209,16 @@ class TrainStep:
         else:
             self.optimizer = torch.optim.AdamW(groups, lr=lr, fused=bool(fused_optimizer and dev.type == "cuda"))
         self.world = torch.distributed.get_world_size(process_group) if torch.distributed.is_initialized() else 1
+        self.masked_embeddings = []
+        if mask_lm_head:
+            if answer_token_id is None:
+                raise ValueError("mask_lm_head needs answer_token_id")
+            self.answer_token_id = int(answer_token_id)
+            self.masked_embeddings = _lm_head_modules(model)
+        row_only = {m.weight: self.answer_token_id for m in self.masked_embeddings if m.weight.requires_grad}
         # single rank: gradients stay ordinary .grad tensors (no bucket indirection, nothing to reduce)
-        self.reducer = GradReducer(self.params, bucket_bytes, process_group, force=force_reducer) if (self.world > 1 or force_reducer) else None
+        self.reducer = (GradReducer(self.params, bucket_bytes, process_group, force=force_reducer, row_only=row_only)
+                        if (self.world > 1 or force_reducer) else None)
 
     def close(self):
         """Detach the DP reducer's autograd hooks and gradient sink (idempotent).  Call before building another TrainStep /
@@ -115,6 +255,8 @@ class TrainStep:
         else:
             loss = self.model(vision_x=vision_x, lang_x=input_ids, attention_mask=attention_mask, labels=labels)[0]
         loss.backward()
+        for m in self.masked_embeddings:          # before the reduction: the reducer then ships one row per masked tensor
+            mask_embedding(m, self.answer_token_id)
         if self.reducer is not None:
             self.reducer.wait()
         if self.max_grad_norm is not None and not self.hip_optimizer:

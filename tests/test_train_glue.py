@@ -1,0 +1,141 @@
+"""CPU: the training-step glue of SURVEY.md section 8 row f4 (otter_amd/train.py) against literal transcriptions of the reference's
+rules -- masking() (instruction_following.py:163-192), find_and_remove_tokens (train_utils.py:276-305), mask_embedding
+(instruction_following.py:228-244), trainable-only checkpoints (train_utils.py:60-67,183-221,234-262)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_host_contract import tiny_model
+
+ANS, EOC, EOS, PAD = 126, 124, 0, 127
+
+
+def literal_masking(ids: np.ndarray) -> np.ndarray:
+    """The reference's per-sample loop, line by line."""
+    want = np.where(ids == EOS, EOS, -100)
+    for i in range(ids.shape[0]):
+        a_all = list(np.where(ids[i] == ANS)[0])
+        e_all = list(np.where(ids[i] == EOC)[0])
+        j = 0
+        for a in a_all:
+            while j < len(e_all) and e_all[j] < a:
+                j += 1
+            if j < len(e_all):
+                want[i, a + 1:e_all[j] + 1] = ids[i, a + 1:e_all[j] + 1]
+                j += 1
+        for a, e in zip(a_all, e_all):
+            want[i, a + 1:e + 1] = ids[i, a + 1:e + 1]
+    want[:, 0] = -100
+    return want
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_masking_random_rows_match_the_reference_loop(seed):
+    """Dense random placement of <answer> / <|endofchunk|> / eos (every ordering the FIFO pointer and the positional zip can meet:
+    nested answers, chunks before answers, unmatched answers, more chunks than answers, specials at columns 0 and T-1)."""
+    from otter_amd.train import masking
+
+    r = np.random.default_rng(seed)
+    B, T = 16, int(r.integers(8, 96))
+    ids = r.integers(1, 120, size=(B, T))
+    for i in range(B):
+        n_sp = int(r.integers(0, max(2, T // 3)))
+        where = r.choice(T, size=n_sp, replace=False)
+        ids[i, where] = r.choice([ANS, EOC, EOS], size=n_sp, p=[0.45, 0.45, 0.1])
+    got = masking(torch.from_numpy(ids), ANS, EOC, EOS).numpy()
+    assert np.array_equal(got, literal_masking(ids))
+
+
+def test_masking_makes_no_host_sync_calls(monkeypatch):
+    """The scan formulation must not fall back to per-row host loops: Tensor.tolist / item / nonzero are never called."""
+    from otter_amd.train import masking
+
+    def boom(*a, **k):
+        raise AssertionError("host synchronisation inside masking()")
+
+    ids = torch.from_numpy(np.random.default_rng(0).integers(1, 128, size=(4, 32)))
+    for name in ("tolist", "item", "nonzero"):
+        monkeypatch.setattr(torch.Tensor, name, boom)
+    masking(ids, ANS, EOC, EOS)
+
+
+def test_find_and_remove_tokens_matches_reference():
+    from otter_amd.train import find_and_remove_tokens
+
+    r = np.random.default_rng(1)
+    B, T = 6, 24
+    ids = torch.from_numpy(r.integers(1, 120, size=(B, T)))
+    ids[0, [3, 9, 20]] = ANS
+    ids[1, 5] = ANS
+    ids[3, [0, 23]] = ANS
+    ids[4, :] = ANS        # a row that disappears entirely
+    labels = torch.from_numpy(r.integers(-100, 120, size=(B, T)))
+    mask = torch.from_numpy(r.integers(0, 2, size=(B, T)))
+    got = find_and_remove_tokens(ids, labels, mask, ANS, PAD)
+    # literal transcription (masked_select per row + pad_sequence)
+    ni, nl, nm = [], [], []
+    for i in range(B):
+        k = ids[i] != ANS
+        ni.append(torch.masked_select(ids[i], k)); nl.append(torch.masked_select(labels[i], k)); nm.append(torch.masked_select(mask[i], k))
+    pad = torch.nn.utils.rnn.pad_sequence
+    want = (pad(ni, batch_first=True, padding_value=PAD), pad(nl, batch_first=True, padding_value=-100), pad(nm, batch_first=True, padding_value=0))
+    for g, w in zip(got, want):
+        assert g.dtype == w.dtype and torch.equal(g, w)
+
+
+def test_mask_embedding_keeps_one_row():
+    from otter_amd.train import mask_embedding
+
+    emb = torch.nn.Embedding(16, 8)
+    emb.weight.grad = torch.randn(16, 8)
+    keep = emb.weight.grad[5].clone()
+    want = emb.weight.grad * torch.nn.functional.one_hot(torch.tensor(5), 16)[:, None]     # the reference's zero_mask product
+    mask_embedding(emb, 5)
+    assert torch.equal(emb.weight.grad, want) and torch.equal(emb.weight.grad[5], keep)
+    frozen = torch.nn.Embedding(4, 4)
+    frozen.weight.requires_grad_(False)
+    mask_embedding(frozen, 1)      # frozen or gradient-less embeddings are left alone, like `if m.weight.requires_grad`
+    assert frozen.weight.grad is None
+
+
+def test_trainable_only_checkpoints_roundtrip(tmp_path):
+    from otter_amd import train as TR
+
+    model = tiny_model()
+    trainable = sorted(n for n, p in model.named_parameters() if p.requires_grad)
+    sd = TR.get_checkpoint(model)
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    assert frozen and not any(n in sd for n in frozen)
+    assert all(n in sd for n in trainable)
+    # final weights: config.json + final_weights.pt with exactly the reference's content (train_utils.py:234-262)
+    path = TR.save_final_weights(model, str(tmp_path / "final"))
+    assert os.path.exists(tmp_path / "final" / "config.json")
+    blob = torch.load(path, map_location="cpu")
+    assert sorted(k for k in blob if k in dict(model.named_parameters())) == trainable
+    # a second model with different trainable weights, same frozen ones
+    other = tiny_model()
+    other.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        for n, p in other.named_parameters():
+            if p.requires_grad:
+                p.add_(1.0)
+    res = TR.load_trained_ckpt(other, path)
+    assert not res.unexpected_keys
+    for (n, a), (_, b) in zip(model.named_parameters(), other.named_parameters()):
+        assert torch.equal(a, b), n
+    # step / epoch checkpoints (train_utils.py:183-221): names, payload keys, previous-checkpoint removal
+    p1 = TR.save_checkpoint(model, str(tmp_path / "ck"), global_step=100, save_steps_interval=100)
+    p2 = TR.save_checkpoint(model, str(tmp_path / "ck"), global_step=200, delete_previous=True, save_steps_interval=100)
+    assert os.path.basename(p1) == "checkpoint_steps_100.pt" and not os.path.exists(p1) and os.path.exists(p2)
+    payload = torch.load(p2, map_location="cpu")
+    assert payload["steps"] == 200 and sorted(k for k in payload["model_state_dict"] if k in dict(model.named_parameters())) == trainable
+    p3 = TR.save_checkpoint(model, str(tmp_path / "ck"), epoch=0)
+    assert os.path.basename(p3) == "checkpoint_0.pt" and set(torch.load(p3, map_location="cpu")) == {"model_state_dict"}
+    TR.load_trained_ckpt(other, p2)
+    # a checkpoint that misses a trainable tensor is an error here (the reference would silently keep the random init)
+    del blob[trainable[0]]
+    torch.save(blob, tmp_path / "short.pt")
+    with pytest.raises(KeyError, match="does not cover"):
+        TR.load_trained_ckpt(other, str(tmp_path / "short.pt"))

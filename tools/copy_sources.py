@@ -10,7 +10,7 @@ layers = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda", 0)
 model = bench.build_model(dev, debug_layers=layers)
 step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0)
-batch = bench.synth_batch(model, 8, 512, dev, 1000)
+batch = bench.synth_batch(model, 8, 512, dev, 1000)[:4]
 for _ in range(2):
     step(*batch)
 torch.cuda.synchronize()

@@ -10,7 +10,7 @@ layers = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 needle = sys.argv[2] if len(sys.argv) > 2 else "CUDAFunctor_add"
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, 0, debug_layers=layers)
-batch = bench.synth_batch(model, 8, 512, dev, 0)
+batch = bench.synth_batch(model, 8, 512, dev, 0)[:4]
 step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16)
 for _ in range(2):
     step(*batch)
