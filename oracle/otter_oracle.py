@@ -249,8 +249,12 @@ def text_time(media_locations, attend_previous=True):
 
 
 def masked_cross_attention_fwd(p, pre, x, media, media_locations=None, attend_previous=True,
-                               only_attend_immediate_media=True, heads=8):
-    """x [B,T,D], media [B,T_img,n,Dv] -> [B,T,D].  modeling_otter.py:262-340 (non-xformers branch)."""
+                               only_attend_immediate_media=True, heads=8, tt=None):
+    """x [B,T,D], media [B,T_img,n,Dv] -> [B,T,D].  modeling_otter.py:262-340 (non-xformers branch).
+    `tt`: a precomputed text_time [B,T] (what `text_time(media_locations, attend_previous)` returns) may be passed instead of
+    media_locations -- the product computes the scan once per forward and shares it between its layers."""
+    if tt is not None and media_locations is None:
+        media_locations = True   # only its presence is used below once tt is given
     B, T_img, n, Dv = media.shape
     xn, c_n = layer_norm_fwd(x, p[pre + "norm.weight"], p[pre + "norm.bias"])
     Wq, Wkv, Wo = p[pre + "to_q.weight"], p[pre + "to_kv.weight"], p[pre + "to_out.weight"]
@@ -268,7 +272,9 @@ def masked_cross_attention_fwd(p, pre, x, media, media_locations=None, attend_pr
     allowed = None
     zero_rows = None
     if media_locations is not None:
-        tt = text_time(media_locations, attend_previous)  # [B,T]
+        if tt is None:
+            tt = text_time(media_locations, attend_previous)  # [B,T]
+        tt = np.asarray(tt).astype(np.int64)
         media_time = np.repeat(np.arange(T_img) + 1, n)  # [M]
         if only_attend_immediate_media:
             allowed = tt[:, None, :, None] == media_time[None, None, None, :]
@@ -314,10 +320,10 @@ def masked_cross_attention_bwd(p, pre, dy, c):
 
 
 def gated_xattn_block_fwd(p, pre, x, media, media_locations=None, attend_previous=True,
-                          only_attend_immediate_media=True, heads=8):
+                          only_attend_immediate_media=True, heads=8, tt=None):
     """modeling_otter.py:373-395."""
     a, c_a = masked_cross_attention_fwd(p, pre + "attn.", x, media, media_locations, attend_previous,
-                                        only_attend_immediate_media, heads)
+                                        only_attend_immediate_media, heads, tt=tt)
     ga = np.tanh(p[pre + "attn_gate"]).astype(x.dtype)
     x1 = a * ga + x
     f, c_ff = layer_norm_fwd(x1, p[pre + "feed_forward.0.weight"], p[pre + "feed_forward.0.bias"])

@@ -1,0 +1,1 @@
+"""Drop-in shim package (see shim/README.md)."""

@@ -98,3 +98,102 @@ def test_grad_reducer_world2_gloo():
     for p in procs:
         p.join(timeout=30)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _otter_worker(rank, world, port, q):
+    """Tiny OtterForConditionalGeneration through TrainStep on 2 ranks: the weight gradients of the fusion modules reach the flat
+    buckets through functional.grad_sink (take / ready), everything else through the post-accumulate hooks; the averaged gradients
+    equal the single-process mean over the two rank losses (DDP semantics, instruction_following.py:311-314,491-494), and with
+    `mask_lm_head` the tied embedding leaves the buckets and only its <answer> row is reduced.  The arithmetic of the fusion
+    modules comes from the numpy oracle (tests/_cpu_backend.py): this checks the PLUMBING of the DP path on the real model graph."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), OTTER_STUB_TOKENIZER="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+
+        from oracle import synth
+        from otter_amd import functional as OF
+        from otter_amd.train import TrainStep
+        from tests import _golden as G
+        from tests._cpu_backend import oracle_backend
+        from tests.test_host_contract import tiny_model
+
+        def build():
+            model = tiny_model()
+            m = G.meta()["otter_tiny"]
+            sd = synth.state_dict_for(m["seed"], {k: tuple(v) for k, v in m["state_dict_shapes"].items()})
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+            return model.train(), m
+
+        model, m = build()
+        vision_x, ids, mask, labels = (torch.from_numpy(a) for a in synth.tiny_batch(m["seed"]))
+        assert ids.shape[0] == world
+        with oracle_backend():
+            # single-process reference: mean over the rank losses
+            ref, _ = build()
+            tot = 0
+            for r in range(world):
+                tot = tot + ref(vision_x=vision_x[r:r + 1], lang_x=ids[r:r + 1], attention_mask=mask[r:r + 1], labels=labels[r:r + 1])[0] / world
+            tot.backward()
+            ref_g = {n: p.grad.clone() for n, p in ref.named_parameters() if p.requires_grad}
+
+            sl = slice(rank, rank + 1)
+            step = TrainStep(model, lr=1e-3, autocast_dtype=None, bucket_bytes=64 << 10, hip_optimizer=False, max_grad_norm=None)
+            red = step.reducer
+            assert red is not None and OF.grad_sink is red and len(red.buckets) >= 3
+            before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+            step.optimizer.step = lambda: None          # look at the reduced gradients before any update
+            step(vision_x[sl], ids[sl], mask[sl], labels[sl])
+            names = {id(p): n for n, p in model.named_parameters()}
+            for p, v in red._view.items():
+                n = names[id(p)]
+                assert p.grad is not None and p.grad.data_ptr() == v.data_ptr(), n
+                assert torch.allclose(p.grad, ref_g[n], rtol=1e-4, atol=1e-6), (n, float((p.grad - ref_g[n]).abs().max()))
+            assert all(b.work is not None for b in red.buckets)
+            step.close()
+
+            # --mask_lm_head: the tied embedding is row-only
+            ans = model.text_tokenizer.encode("<answer>")[-1]
+            step2 = TrainStep(model, lr=1e-3, autocast_dtype=None, bucket_bytes=64 << 10, hip_optimizer=False, max_grad_norm=None,
+                              mask_lm_head=True, answer_token_id=ans)
+            wte = model.lang_encoder.transformer.wte.weight
+            assert wte not in step2.reducer._owner and wte in step2.reducer.row_only
+            step2.optimizer.step = lambda: None
+            step2(vision_x[sl], ids[sl], mask[sl], labels[sl])
+            want = torch.zeros_like(wte)
+            want[ans] = ref_g["lang_encoder.transformer.wte.weight"][ans]
+            assert torch.allclose(wte.grad, want, rtol=1e-4, atol=1e-7)
+            assert float(wte.grad[ans].abs().max()) > 0
+            step2.close()
+            assert OF.grad_sink is None
+
+            # a real optimizer step keeps the replicas identical
+            step3 = TrainStep(model, lr=1e-3, autocast_dtype=None, bucket_bytes=64 << 10, hip_optimizer=False)
+            step3(vision_x[sl], ids[sl], mask[sl], labels[sl])
+            chk = torch.stack([p.detach().double().sum() for p in model.parameters() if p.requires_grad])
+            both = [torch.zeros_like(chk) for _ in range(world)]
+            dist.all_gather(both, chk)
+            assert torch.equal(both[0], both[1])
+            assert any(not torch.equal(p.detach(), before[n]) for n, p in model.named_parameters() if p.requires_grad)
+            step3.close()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_otter_trainstep_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_otter_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=280) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

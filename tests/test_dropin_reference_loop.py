@@ -1,0 +1,191 @@
+"""CPU (build container only -- needs /root/reference): the north-star "drops into pipeline/train/instruction_following.py
+unchanged" claim, executed.  The reference's own training script is imported with `shim/` in front of it on sys.path, so its
+`from src.otter_ai.models.otter.modeling_otter import OtterForConditionalGeneration` (:49) resolves to otter_amd; third-party
+modules that are not installed here and that the Otter branch never calls (deepspeed, wandb, peft, the webdataset loader) are
+stubbed.  Then the reference's `train_one_epoch` (:116-251) -- its own masking(), forward_pass(), accelerate backward, clip,
+optimizer / scheduler stepping -- drives a tiny OtterForConditionalGeneration for two optimizer steps, and the resulting weights
+are compared with otter_amd.train.TrainStep on the same batches.
+
+There is no GPU here and the product has no CPU path, so the arithmetic of the fusion modules comes from the numpy oracle through
+tests/_cpu_backend.py (test infrastructure): what this test pins is the CONTRACT -- import path, constructor, attributes the loop
+reads (`lang_encoder.__class__.__name__`, `transformer.wte`, `.dtype`, `config.save_pretrained`), forward signature and `[0]` = loss,
+parameter names seen by the reference's get_grouped_params / get_checkpoint / mask_embedding."""
+import importlib
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pipeline", "train")), reason="needs the reference checkout (build container)")
+
+
+@pytest.fixture(scope="module")
+def ref_script():
+    import accelerate  # noqa: F401  (real)
+    import transformers  # noqa: F401
+    # everything the script pulls from transformers is resolved BEFORE the stubs go in: transformers probes for deepspeed / peft with
+    # importlib.util.find_spec while its lazy modules load, and a stub would read as "installed"
+    import transformers.trainer_utils  # noqa: F401
+    from transformers import (AutoProcessor, AutoTokenizer, CLIPImageProcessor, FuyuImageProcessor, LlamaForCausalLM,  # noqa: F401
+                              get_constant_schedule_with_warmup, get_cosine_schedule_with_warmup, get_linear_schedule_with_warmup)
+    try:
+        from transformers import IdeficsForVisionText2Text  # noqa: F401
+        import transformers.models.idefics.processing_idefics  # noqa: F401
+    except Exception:
+        pass
+
+    saved_path, saved_mods = list(sys.path), dict(sys.modules)
+    for name in ("deepspeed", "wandb", "peft"):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        sys.modules[name] = m
+    sys.modules["peft"].LoraConfig = sys.modules["peft"].TaskType = sys.modules["peft"].PeftModel = object
+    sys.modules["peft"].get_peft_model = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("peft is not installed"))
+    data = types.ModuleType("pipeline.mimicit_utils.data")          # the webdataset / torchvision loader: replaced by synthetic batches
+    data.get_data = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError)
+    sys.modules["pipeline.mimicit_utils.data"] = data
+    for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+        del sys.modules[k]
+    sys.path[:0] = [os.path.join(ROOT, "shim"), ROOT, REF]
+    try:
+        mod = importlib.import_module("pipeline.train.instruction_following")
+        yield mod
+    finally:
+        sys.path[:] = saved_path
+        for k in list(sys.modules):
+            if k not in saved_mods:
+                del sys.modules[k]
+
+
+class _Loader:
+    """What train_one_epoch needs of a MIMIC-IT dataloader: len(), .dataset, iteration over collated batches
+    (mimicit_dataset.py collate: net_input = {patch_images [B,T_img,F,3,H,W], input_ids, attention_masks})."""
+
+    def __init__(self, batches):
+        self.batches = batches
+        self.dataset = list(range(sum(b["net_input"]["input_ids"].shape[0] for b in batches)))
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for b in self.batches:
+            yield {"net_input": dict(b["net_input"]), "task_group": list(b["task_group"])}
+
+
+def _batches(model, n, seed0):
+    from oracle import synth
+
+    tok = model.text_tokenizer
+    ans, eoc = tok.encode("<answer>")[-1], model.eoc_token_id
+    out = []
+    for i in range(n):
+        vision_x, ids, mask, _ = synth.tiny_batch(seed0 + i)
+        ids = ids.copy()
+        ids[:, 5] = ans
+        ids[:, 11] = eoc
+        out.append({"net_input": {"patch_images": torch.from_numpy(vision_x), "input_ids": torch.from_numpy(ids),
+                                  "attention_masks": torch.from_numpy(mask)}, "task_group": ["synthetic"] * ids.shape[0]})
+    return out
+
+
+def _build():
+    from oracle import synth
+    from tests import _golden as G
+    from tests.test_host_contract import tiny_model
+
+    model = tiny_model()
+    m = G.meta()["otter_tiny"]
+    sd = synth.state_dict_for(m["seed"], {k: tuple(v) for k, v in m["state_dict_shapes"].items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    return model
+
+
+@pytest.mark.parametrize("mask_lm_head", [False, True])
+def test_reference_train_one_epoch_drives_otter_amd(ref_script, mask_lm_head, tmp_path):
+    IF = ref_script
+    import otter_amd.modeling_otter as MO
+    from accelerate import Accelerator
+    from otter_amd import train as TR
+    from tests._cpu_backend import oracle_backend
+
+    # the reference script's names are otter_amd's classes
+    assert IF.OtterForConditionalGeneration is MO.OtterForConditionalGeneration
+    assert IF.FlamingoForConditionalGeneration is MO.OtterForConditionalGeneration
+    tu = sys.modules["pipeline.train.train_utils"]
+
+    model = _build()
+    batches = _batches(model, 2, seed0=11)
+    args = types.SimpleNamespace(model_name="otter", total_training_steps=2, gradient_accumulation_steps=1, rank=0, world_size=1, batch_size=2,
+                                 remove_answer_token=False, remove_eos_token=False, mask_lm_head=mask_lm_head, distributed_type="NO",
+                                 report_to_wandb=False, save_steps_interval=-1, logging_steps=1, num_epochs=1, external_save_dir=str(tmp_path),
+                                 save_hf_model=False)
+    accelerator = Accelerator(gradient_accumulation_steps=1, mixed_precision="no", cpu=True)
+    lr, wd = 1e-3, 0.1
+    optimizer = torch.optim.AdamW(tu.get_grouped_params(model, wd=wd), lr=lr)      # the reference's grouping rule on otter_amd's names
+    sched = IF.get_constant_schedule_with_warmup(optimizer, num_warmup_steps=0)
+    losses = []
+    orig_forward = model.forward
+
+    def recording_forward(*a, **k):
+        out = orig_forward(*a, **k)
+        losses.append(float(out[0].detach()))
+        return out
+
+    model.forward = recording_forward
+    with oracle_backend():
+        IF.train_one_epoch(args, model, 0, [_Loader(batches)], model.text_tokenizer, optimizer, sched, accelerator.device, accelerator, sys.modules["wandb"])
+    model.forward = orig_forward
+    assert len(losses) == 2 and all(np.isfinite(losses))
+
+    # the same two steps through otter_amd's own TrainStep (torch AdamW on CPU, fp32, clip 1.0)
+    twin = _build()
+    tok = twin.text_tokenizer
+    ans = tok.encode("<answer>")[-1]
+    step = TR.TrainStep(twin, lr=lr, weight_decay=wd, max_grad_norm=1.0, autocast_dtype=None, hip_optimizer=False,
+                        mask_lm_head=mask_lm_head, answer_token_id=ans)
+    twin_losses = []
+    with oracle_backend():
+        for b in batches:
+            ni = b["net_input"]
+            labels = TR.masking(ni["input_ids"], ans, twin.eoc_token_id, tok.encode(tok.eos_token)[-1])
+            twin_losses.append(float(step(ni["patch_images"], ni["input_ids"], ni["attention_masks"], labels)))
+    assert np.allclose(losses, twin_losses, rtol=1e-6, atol=0), (losses, twin_losses)
+    for (n, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
+    assert losses[1] != losses[0]
+
+    # the reference's own checkpoint writer on the trained model == otter_amd.train's (same keys, same tensors)
+    # (the reference pins an older accelerate whose Accelerator.save took `is_main_process`; the installed one does not)
+    accelerator.save = lambda obj, f, is_main_process=True, **k: torch.save(obj, f)
+    tu.save_final_weights(model, args, accelerator)
+    ref_blob = torch.load(os.path.join(str(tmp_path), "final_weights.pt"), map_location="cpu")
+    ours = TR.get_checkpoint(twin)
+    assert sorted(ref_blob) == sorted(ours)
+    assert os.path.exists(os.path.join(str(tmp_path), "config.json"))
+    fresh = _build()
+    TR.load_trained_ckpt(fresh, os.path.join(str(tmp_path), "final_weights.pt"))
+    for (n, a), (_, b) in zip(model.named_parameters(), fresh.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), n
+
+
+def test_reference_forward_pass_signature(ref_script):
+    """forward_pass (:73-103) calls model(vision_x=images.to(autocast_type), lang_x=, attention_mask=, labels=)[0]."""
+    IF = ref_script
+    from oracle import synth
+    from tests._cpu_backend import oracle_backend
+
+    model = _build()
+    vision_x, ids, mask, labels = (torch.from_numpy(a) for a in synth.tiny_batch(3))
+    args = types.SimpleNamespace(model_name="otter")
+    with oracle_backend():
+        loss = IF.forward_pass(args, model, model.text_tokenizer, vision_x, ids, mask, labels, "cpu", torch.float32, {})
+        want = model(vision_x=vision_x, lang_x=ids, attention_mask=mask, labels=labels).loss
+    assert loss.ndim == 0 and float(loss) == float(want)
