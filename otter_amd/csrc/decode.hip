@@ -102,6 +102,16 @@ int otter_decode_attn(const void* q, int64_t q_batch_stride, int64_t q_head_stri
     a.o = (bf16_t*)o; a.o_bs = o_batch_stride; a.o_hs = o_head_stride;
     a.slopes = alibi_slopes; a.kvalid = key_valid; a.B = (int)B; a.H = (int)H; a.Sk = (int)Sk; a.scale = scale;
     const size_t smem = sizeof(float) * (size_t)(Sk > 2 * HD ? Sk : 2 * HD);
+    if (smem > 32768) {
+        // above the default dynamic-LDS allowance the launch needs the opt-in (64 KiB of scores + the kernel's 528 B of static LDS at
+        // Sk = 16384, of the CU's 160 KiB).  Set once per process; thread-safe (a benign repeated call).
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute((const void*)decode_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4);
+            OTTER_REQUIRE(e == hipSuccess, "decode_attn: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(e));
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL(decode_attn_kernel, dim3((unsigned)H, (unsigned)B), dim3(NT), smem, (hipStream_t)stream, a);
     OTTER_CHECK_LAUNCH("decode_attn");
     return OTTER_OK;

@@ -166,6 +166,8 @@ __global__ void sqrelu_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __
 }
 
 // out[b, s, :] = idx[b, s] < 0 ? word[b, s, :] : patch[b, idx[b, s], :]     (one pass: the clone and the scatter)
+// An index >= P is never dereferenced: the row is filled with NaN (the reference's advanced indexing raises for it; the host
+// wrapper validates the range before the launch, this is the in-kernel backstop -- same policy as loss.hip's label >= V).
 template <typename TW, typename TP>
 __global__ void scatter_rows_kernel(const TW* __restrict__ word, const TP* __restrict__ patch, const int64_t* __restrict__ idx, TW* __restrict__ out,
                                     int64_t S, int64_t P, int64_t D, int64_t nch) {
@@ -175,7 +177,11 @@ __global__ void scatter_rows_kernel(const TW* __restrict__ word, const TP* __res
     const int64_t b = row / S, j = idx[row];
     float v[8];
     if (j < 0) Vec8<TW>::load(word + row * D + 8 * c, v);
-    else Vec8<TP>::load(patch + (b * P + j) * D + 8 * c, v);
+    else if (j < P) Vec8<TP>::load(patch + (b * P + j) * D + 8 * c, v);
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_nanf("");
+    }
     Vec8<TW>::store(out + row * D + 8 * c, v);
 }
 

@@ -726,10 +726,12 @@ class PersimmonAttentionFn(torch.autograd.Function):
         o, lse = ops.flash_attn_fwd(q, k, v, None, None, scale, True)            # [B,S,H,128]
         ctx.save_for_backward(qkv, stats, q, k, v, o, lse, gqf, gkf, cos, sin)
         ctx.cfg = (H, rot, scale, gq.dtype)
-        return o[..., :64].reshape(B, S, H * 64)
+        k_c, v_c = k[..., :64], v[..., :64]          # normalised + rotated keys and the values, for a KV cache (not differentiable)
+        ctx.mark_non_differentiable(k_c, v_c)
+        return o[..., :64].reshape(B, S, H * 64), k_c, v_c
 
     @staticmethod
-    def backward(ctx, dctx):
+    def backward(ctx, dctx, _dk, _dv):
         qkv, stats, q, k, v, o, lse, gqf, gkf, cos, sin = ctx.saved_tensors
         H, rot, scale, pdt = ctx.cfg
         B, S, _ = qkv.shape
@@ -741,9 +743,13 @@ class PersimmonAttentionFn(torch.autograd.Function):
         return dqkv, dgq.to(pdt), dbq.to(pdt), dgk.to(pdt), dbk.to(pdt), None, None, None, None, None, None
 
 
-def persimmon_attention(qkv, q_ln, k_ln, cos, sin, n_heads, rot, scale):
-    return PersimmonAttentionFn.apply(qkv, q_ln.weight, q_ln.bias, k_ln.weight, k_ln.bias, cos.contiguous(), sin.contiguous(), n_heads, rot,
-                                      q_ln.eps, scale)
+def persimmon_attention(qkv, q_ln, k_ln, cos, sin, n_heads, rot, scale, want_kv=False):
+    """ctx [B,S,H*64], or (ctx, k [B,H,S,64], v [B,H,S,64]) with want_kv (the layout of the plain path's cache)."""
+    ctx, k_c, v_c = PersimmonAttentionFn.apply(qkv, q_ln.weight, q_ln.bias, k_ln.weight, k_ln.bias, cos.contiguous(), sin.contiguous(), n_heads,
+                                               rot, q_ln.eps, scale)
+    if want_kv:
+        return ctx, k_c.transpose(1, 2), v_c.transpose(1, 2)
+    return ctx
 
 
 class ScatterPatchRowsFn(torch.autograd.Function):

@@ -100,6 +100,9 @@ class PersimmonAttention(nn.Module):
         H, d = self.n_heads, self.head_dim
         qkv = OF.trainable_linear(self.query_key_value, x)                      # [B,S,H*3*d], per head (q | k | v)
         if hip:
+            if use_cache:
+                ctx, k, v = OF.persimmon_attention(qkv, self.q_layernorm, self.k_layernorm, cos, sin, H, self.rot, self.scale, want_kv=True)
+                return OF.trainable_linear(self.dense, ctx), (k, v)
             ctx = OF.persimmon_attention(qkv, self.q_layernorm, self.k_layernorm, cos, sin, H, self.rot, self.scale)
             return OF.trainable_linear(self.dense, ctx), None
         q5 = qkv.view(B, S, H, 3, d)
@@ -137,9 +140,9 @@ class PersimmonDecoderLayer(nn.Module):
         if hip:
             n1, n2 = self.input_layernorm, self.post_attention_layernorm
             a = OF.layer_norm(x, n1.weight, n1.bias, n1.eps, torch.bfloat16)
-            b, _ = self.self_attn(a, cos, sin, hip=True)
+            b, new_past = self.self_attn(a, cos, sin, use_cache=use_cache, hip=True)
             x, m = OF.add_layer_norm(x, b, n2.weight, n2.bias, n2.eps, torch.bfloat16)   # x = x + b ; m = LN(x)  (one pass)
-            return x + self.mlp(m), None
+            return x + self.mlp(m), new_past
         b, new_past = self.self_attn(self.input_layernorm(x), cos, sin, attn_mask=attn_mask, past_key_value=past_key_value, use_cache=use_cache)
         x = x + b
         return x + self.mlp(self.post_attention_layernorm(x)), new_past
@@ -195,7 +198,8 @@ class PersimmonModel(PersimmonPreTrainedModel):
                 return_dict=True, **unused):
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You have to specify either input_ids or inputs_embeds")
-        use_cache = bool(use_cache) if use_cache is not None else False
+        # HF / reference default: the config's use_cache, in train mode too; the cache entries are views, not copies
+        use_cache = bool(use_cache) if use_cache is not None else bool(getattr(self.config, "use_cache", True))
         x = self.embed_tokens(input_ids) if inputs_embeds is None else inputs_embeds
         B, S = x.shape[:2]
         s_past = 0
@@ -217,7 +221,7 @@ class PersimmonModel(PersimmonPreTrainedModel):
                 am = None
         # HIP path: causal only, like the reference's flash_attn_func(causal=True) which never sees the padding mask
         # (modeling_persimmon.py:310): with right padding the real positions are identical; left padding takes the plain path
-        hip = self.layers[0].self_attn.hip_ok(x, s_past, default_pos) and (am is None or bool(am[:, 0].all())) and not use_cache
+        hip = self.layers[0].self_attn.hip_ok(x, s_past, default_pos) and (am is None or bool(am[:, 0].all()))
         mask = None
         if not hip:
             neg = torch.finfo(torch.float32).min
@@ -275,6 +279,24 @@ class PersimmonForCausalLM(PersimmonPreTrainedModel):
                 loss = F.cross_entropy(flat.float(), lab, ignore_index=-100)
         return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=out.past_key_values)
 
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, **generate_kwargs):
+        """Text-only decoding (transformers 5.x no longer gives PreTrainedModel a generate()): otter_amd/generation.py over this model."""
+        from .generation import generate_tokens
+
+        use_cache = bool(generate_kwargs.pop("use_cache", getattr(self.config, "use_cache", True)))
+
+        def step(ids, mask, past, beam_idx):
+            if use_cache and past is not None:
+                if beam_idx is not None:
+                    past = tuple(tuple(t.index_select(0, beam_idx) for t in layer) for layer in past)
+                out = self(input_ids=ids[:, -1:], attention_mask=mask, past_key_values=past, use_cache=True)
+            else:
+                out = self(input_ids=ids, attention_mask=mask, use_cache=use_cache)
+            return out.logits[:, -1, :], (out.past_key_values if use_cache else None)
+
+        return generate_tokens(step, input_ids, attention_mask, **generate_kwargs)
+
 
 class FuyuPreTrainedModel(PreTrainedModel):
     config_class = FuyuConfig
@@ -319,11 +341,19 @@ class FuyuForCausalLM(FuyuPreTrainedModel):
         if word_embeddings.shape[0] != len(continuous_embeddings):
             raise ValueError(f"Batch sizes must match! Got {len(continuous_embeddings)=} and {word_embeddings.shape[0]=}")
         B = word_embeddings.shape[0]
-        for b in range(B):
-            n_idx = int((image_patch_input_indices[b] >= 0).sum())
-            if n_idx > continuous_embeddings[b].shape[0]:
-                raise ValueError(f"Number of continuous embeddings {continuous_embeddings[b].shape=} does not match number of continuous "
-                                 f"token ids {n_idx} in batch element {b}.")
+        idx = image_patch_input_indices
+        n_rows = torch.tensor([c.shape[0] for c in continuous_embeddings], device=idx.device)
+        n_idx = (idx >= 0).sum(dim=1)
+        # one host synchronisation for both checks (the reference's per-sample loop has one per sample)
+        bad_count, bad_range = (torch.stack([(n_idx > n_rows).any(), (idx.max(dim=1).values >= n_rows).any()]).tolist() if B else (False, False))
+        if bad_count:
+            b = int(torch.nonzero(n_idx > n_rows)[0])
+            raise ValueError(f"Number of continuous embeddings {continuous_embeddings[b].shape=} does not match number of continuous "
+                             f"token ids {int(n_idx[b])} in batch element {b}.")
+        if bad_range:   # the reference's `continuous_embeddings[b][src]` raises IndexError for these
+            b = int(torch.nonzero(idx.max(dim=1).values >= n_rows)[0])
+            raise IndexError(f"image_patch_input_indices of batch element {b} reach {int(idx[b].max())}, but it has only "
+                             f"{continuous_embeddings[b].shape[0]} continuous embeddings")
         if word_embeddings.is_cuda and all(c.shape[0] == continuous_embeddings[0].shape[0] for c in continuous_embeddings):
             return OF.scatter_patch_rows(word_embeddings, torch.stack(list(continuous_embeddings), 0), image_patch_input_indices)
         out = word_embeddings.clone()
@@ -332,6 +362,47 @@ class FuyuForCausalLM(FuyuPreTrainedModel):
             src = image_patch_input_indices[b][dst]
             out[b, dst] = continuous_embeddings[b][src].to(out.dtype)
         return out
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, image_patches=None,
+                                      image_patches_indices=None, **kwargs):
+        """modeling_fuyu.py:145-175 (the pinned transformers' hook): with a cache only the last token is fed and the patches are dropped."""
+        if past_key_values is not None:
+            input_ids = input_ids[:, -1:]
+        return {"input_ids": input_ids, "past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"), "attention_mask": attention_mask,
+                "image_patches": image_patches if past_key_values is None else None,
+                "image_patches_indices": image_patches_indices if past_key_values is None else None}
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, image_patches=None, image_patches_indices: Optional[torch.Tensor] = None,
+                 attention_mask: Optional[torch.Tensor] = None, **generate_kwargs):
+        """`model.generate(**processor_outputs, max_new_tokens=...)` as the reference's OtterHD inference calls it
+        (pipeline/demos/demo_models.py:171; the pinned transformers mixes GenerationMixin into PreTrainedModel, 5.x no longer does).
+        Decoding = otter_amd/generation.py (greedy / beam / sampling, the same restatement OtterForConditionalGeneration.generate uses).
+        The image patches enter on the prompt pass only; with `use_cache` (default: the config's) later steps feed one token against
+        the KV cache, without it the whole sequence is re-run with the patch positions of the prompt and -1 for the new tokens."""
+        from .generation import generate_tokens
+
+        use_cache = bool(generate_kwargs.pop("use_cache", getattr(self.config.text_config, "use_cache", True)))
+        L0 = input_ids.shape[1]
+        nb = int(generate_kwargs.get("num_beams", 1) or 1)
+        patches, idx0 = image_patches, image_patches_indices
+        if nb > 1 and patches is not None:          # every beam of a sample sees that sample's image
+            patches = (patches.repeat_interleave(nb, dim=0) if torch.is_tensor(patches) else [p for p in patches for _ in range(nb)])
+            idx0 = idx0.repeat_interleave(nb, dim=0)
+
+        def step(ids, mask, past, beam_idx):
+            if use_cache and past is not None:
+                if beam_idx is not None:
+                    past = tuple(tuple(t.index_select(0, beam_idx) for t in layer) for layer in past)
+                out = self(input_ids=ids[:, -1:], attention_mask=mask, past_key_values=past, use_cache=True)
+            else:
+                idx = idx0
+                if idx is not None and ids.shape[1] > L0:
+                    idx = torch.cat([idx, idx.new_full((idx.shape[0], ids.shape[1] - L0), -1)], dim=1)
+                out = self(input_ids=ids, image_patches=patches, image_patches_indices=idx, attention_mask=mask, use_cache=use_cache)
+            return out.logits[:, -1, :], (out.past_key_values if use_cache else None)
+
+        return generate_tokens(step, input_ids, attention_mask, **generate_kwargs)
 
     def forward(self, input_ids=None, labels=None, image_patches=None, image_patches_indices=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, use_cache=None, return_dict=True, **unused):

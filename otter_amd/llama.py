@@ -82,10 +82,19 @@ class LlamaRMSNorm(nn.Module):
 class _FusedFrozenLinear:
     """x -> x [W_1; W_2; ...]^T for several bias-free FROZEN nn.Linear modules sharing their input (q|k|v, gate|up): one GEMM
     instead of two or three, output slices contiguous in one buffer; the concatenated weight and its transpose (for the only
-    backward product of a frozen layer, dx = dy W) are built once per weight version, in the compute dtype."""
+    backward product of a frozen layer, dx = dy W) are built once per weight version, in the compute dtype.
+
+    Memory: the fused copy and its transpose are PERSISTENT duplicates of frozen weights -- for LLaMA-7B in bf16 about
+    2 x 8.6 GB on top of the 13 GB model (288 GB of HBM per MI355X is what this layout is sized for).  `release()` drops them (they are
+    rebuilt on the next forward); LlamaForCausalLM.release_fused_copies() does it for the whole model and runs automatically when the
+    module is moved or cast (`.to()`, `.cpu()`, `.half()`: nn.Module._apply)."""
 
     def __init__(self, mods: List[nn.Linear]):
         self.mods = mods
+        self._key = None
+        self._w = self._wt = None
+
+    def release(self):
         self._key = None
         self._w = self._wt = None
 
@@ -254,7 +263,9 @@ class LlamaModel(LlamaPreTrainedModel):
                 use_cache=None, return_dict=True, **unused):
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
-        use_cache = bool(use_cache) if use_cache is not None else bool(getattr(self.config, "use_cache", False)) and not self.training
+        # HF / reference default: the config's use_cache, in train mode too; the cache entries are views of buffers the
+        # attention path produces anyway
+        use_cache = bool(use_cache) if use_cache is not None else bool(getattr(self.config, "use_cache", True))
         x = self.embed_tokens(input_ids) if inputs_embeds is None else inputs_embeds
         B, S = x.shape[:2]
         s_past = 0
@@ -337,6 +348,22 @@ class LlamaForCausalLM(LlamaPreTrainedModel):
 
     def set_decoder(self, decoder):
         self.model = decoder
+
+    def release_fused_copies(self):
+        """Free every cached duplicate of the frozen weights (fused q|k|v and gate|up matrices, transposed dgrad copies: ~17 GB for
+        LLaMA-7B in bf16, see _FusedFrozenLinear); they are rebuilt lazily by the next training forward."""
+        from .mpt import FrozenAwareLinear
+
+        for m in self.modules():
+            if isinstance(m, FrozenAwareLinear):
+                m.release_copies()
+            for f in (getattr(m, "_gu", None), getattr(m, "_qkv", None)):
+                if isinstance(f, _FusedFrozenLinear):
+                    f.release()
+
+    def _apply(self, fn, *a, **k):
+        self.release_fused_copies()
+        return super()._apply(fn, *a, **k)
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, return_dict=True, **unused):

@@ -141,6 +141,15 @@ class FrozenAwareLinear(nn.Linear):
             self._fz_w, self._fz_wt, self._fz_key = wc, wc.t().contiguous(), key
         return self._fz_w, self._fz_wt
 
+    def release_copies(self):
+        """Drop the cached compute-dtype / transposed copies (rebuilt on the next training forward)."""
+        self._fz_w = self._fz_wt = self._fz_key = None
+
+    def _apply(self, fn, *a, **k):
+        # .to() / .cpu() / .half(): the copies would otherwise stay behind on the old device in the old dtype (ADVICE r2)
+        self.release_copies()
+        return super()._apply(fn, *a, **k)
+
     def forward(self, x):
         w = self.weight
         if (w.requires_grad or self.bias is not None or not x.is_cuda or not torch.is_grad_enabled() or not x.requires_grad

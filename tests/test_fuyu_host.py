@@ -68,3 +68,62 @@ def test_cached_decode_equals_full_forward():
             steps.append(out.logits)
     inc = torch.cat(steps, 1)
     assert float((inc - full).abs().max() / full.abs().max()) < 1e-5
+
+
+def _greedy_reference(model, ids, patches, idx, n_new):
+    """Plain argmax loop over full forwards (no cache): what transformers' greedy generate computes for this model."""
+    t = torch.from_numpy
+    ids_t, idx_t = t(ids), t(idx)
+    with torch.no_grad():
+        for _ in range(n_new):
+            logits = model(input_ids=ids_t, image_patches=t(patches), image_patches_indices=idx_t, use_cache=False).logits
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+            ids_t = torch.cat([ids_t, nxt], 1)
+            idx_t = torch.cat([idx_t, torch.full_like(nxt, -1)], 1)
+    return ids_t
+
+
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_fuyu_generate_greedy(use_cache):
+    """FuyuForCausalLM.generate(**processor_outputs, max_new_tokens=) -- the OtterHD inference call
+    (pipeline/demos/demo_models.py:171) -- in both decode modes, token-exact against the plain argmax loop; the image patches
+    are consumed on the prompt pass only."""
+    model = _model().eval()
+    ids, patches, idx, mask, _ = tiny_fuyu_batch()
+    P = 14
+    want = _greedy_reference(model, ids[:, :P], patches, idx[:, :P], 5)
+    t = torch.from_numpy
+    got = model.generate(input_ids=t(ids[:, :P]), image_patches=t(patches), image_patches_indices=t(idx[:, :P]), max_new_tokens=5,
+                         use_cache=use_cache, eos_token_id=-1)
+    assert torch.equal(got, want)
+    prep = model.prepare_inputs_for_generation(t(ids), past_key_values=((None, None),), image_patches=t(patches), image_patches_indices=t(idx))
+    assert prep["input_ids"].shape[1] == 1 and prep["image_patches"] is None and prep["image_patches_indices"] is None
+
+
+def test_fuyu_generate_beams_and_out_of_range_indices():
+    model = _model().eval()
+    ids, patches, idx, _, _ = tiny_fuyu_batch()
+    t = torch.from_numpy
+    P = 14
+    a = model.generate(input_ids=t(ids[:, :P]), image_patches=t(patches), image_patches_indices=t(idx[:, :P]), max_new_tokens=4, num_beams=3,
+                       use_cache=True, eos_token_id=-1)
+    b = model.generate(input_ids=t(ids[:, :P]), image_patches=t(patches), image_patches_indices=t(idx[:, :P]), max_new_tokens=4, num_beams=3,
+                       use_cache=False, eos_token_id=-1)
+    assert a.shape == (ids.shape[0], P + 4) and torch.equal(a, b)
+    # ADVICE r2: an index >= the number of patches is an IndexError (the reference's advanced indexing raises), never a silent read
+    bad = idx.copy()
+    bad[0, np.argmax(bad[0] >= 0)] = patches.shape[1]
+    with pytest.raises(IndexError, match="continuous embeddings"):
+        model(input_ids=t(ids), image_patches=t(patches), image_patches_indices=t(bad))
+
+
+def test_persimmon_use_cache_follows_config():
+    """past_key_values are returned whenever config.use_cache is true (HF / reference default), in train mode too."""
+    model = _model().train()
+    ids, patches, idx, _, _ = tiny_fuyu_batch()
+    t = torch.from_numpy
+    out = model(input_ids=t(ids), image_patches=t(patches), image_patches_indices=t(idx))
+    assert bool(model.config.text_config.use_cache) and out.past_key_values is not None and len(out.past_key_values) == model.config.text_config.num_hidden_layers
+    assert model(input_ids=t(ids), image_patches=t(patches), image_patches_indices=t(idx), use_cache=False).past_key_values is None
+    txt = model.language_model.generate(t(ids[:, :6]), max_new_tokens=3, eos_token_id=-1)
+    assert txt.shape == (ids.shape[0], 9)

@@ -104,3 +104,39 @@ def test_unsupported_arguments_are_loud(pair):
         generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beam_groups=2, diversity_penalty=0.5)
     with pytest.raises(NotImplementedError):
         generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beams=2, do_sample=True)
+
+
+@pytest.mark.parametrize("kw", [dict(num_beams=1, max_new_tokens=10), dict(num_beams=3, max_new_tokens=10, no_repeat_ngram_size=3)])
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_left_padded_mixed_length_batch(pair, kw, use_cache):
+    """the reference's benchmark wrappers tokenize with padding_side='left' (pipeline/benchmarks/models/otter_image.py), so a
+    batch holds prompts of different lengths padded on the LEFT.  Greedy and beam search, with and without the KV cache, against
+    transformers' generate on the same left-padded batch (position ids follow the mask there; RoPE is relative, so the tokens agree)."""
+    from otter_amd.generation import generate_tokens
+
+    cfg, ref, mine = pair
+    g = torch.Generator().manual_seed(321)
+    L = 9
+    ids = torch.randint(3, cfg.vocab_size, (3, L), generator=g)
+    mask = torch.ones_like(ids)
+    for row, n_pad in enumerate([0, 3, 5]):
+        ids[row, :n_pad] = 0
+        mask[row, :n_pad] = 0
+    with torch.no_grad():
+        want = ref.generate(input_ids=ids, attention_mask=mask, eos_token_id=1, pad_token_id=0, use_cache=True, do_sample=False, **kw)
+        got = generate_tokens(_step_for(mine, use_cache), ids, mask, eos_token_id=1, pad_token_id=0, **kw)
+    assert torch.equal(got, want), (got.tolist(), want.tolist())
+
+
+def test_llama_use_cache_follows_config(pair):
+    """`past_key_values` come back whenever config.use_cache is true, in train mode too (HF / the reference's default)."""
+    cfg, _, mine = pair
+    ids = torch.randint(3, cfg.vocab_size, (2, 5), generator=torch.Generator().manual_seed(4))
+    try:
+        mine.train()
+        with torch.no_grad():
+            assert bool(cfg.use_cache) and mine(input_ids=ids).past_key_values is not None
+            assert mine(input_ids=ids, use_cache=False).past_key_values is None
+    finally:
+        mine.eval()
+    mine.release_fused_copies()      # idempotent on a model that never built any
