@@ -142,6 +142,16 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
 /* selects the bf16 kernel schedule: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 register-staged,
  * 3 = 256x256 direct-to-LDS (global_load_lds).  Process-wide; for A/B measurements. */
 int otter_gemm_set_variant(int variant);
+/* 1 if `variant` is compiled into this library.  The product build carries 0-3, 13, 25, 26 (the kernels pick_cfg can choose);
+ * the earlier kernel generations (4-12, 14-23, 27-29) live in the tools-only experimental build
+ * (`python -m otter_amd.build --experimental` -> lib/libotter_hip_experimental.so, -DOTTER_EXPERIMENTAL). */
+int otter_gemm_variant_available(int variant);
+/* Caps the persistent GEMM grids at `cus` workgroups (0 = every CU of the device, the default; values below 8 are raised to 8).
+ * Returns the grid size now in effect.  Used by the data-parallel step: with `cus` a little below the device's CU count, RCCL's
+ * all-reduce kernels get CUs of their own and run concurrently with the backward GEMMs (nothing to match in the reference:
+ * torch DDP relies on the GPU scheduler).  Process-wide, like the other otter_gemm_set_* switches: set it from the thread that
+ * launches the GEMMs, between steps. */
+int otter_gemm_set_cu_budget(int cus);
 /* diagnostics for roofline ablations (results are WRONG when non-zero): bit0 = no global loads inside the K loop,
  * bit1 = no MFMAs.  Never set by the product path. */
 int otter_gemm_set_debug(int flags);

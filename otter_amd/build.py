@@ -44,6 +44,19 @@ def build_diag(mask: int, verbose: bool = True) -> str:
     return out
 
 
+def build_experimental(verbose: bool = True) -> str:
+    """Tools-only library with every GEMM schedule of rounds 1-2 (-DOTTER_EXPERIMENTAL: variants 4-12, 14-23, 27-29) ->
+    lib/libotter_hip_experimental.so.  tools/gemm_*.py load it through OTTER_LIB_PATH; the product never does."""
+    build(verbose=verbose)
+    cc = hipcc()
+    obj = os.path.join(LIBDIR, "gemm_experimental.o")
+    out = os.path.join(LIBDIR, "libotter_hip_experimental.so")
+    subprocess.check_call([cc, *FLAGS, "-DOTTER_EXPERIMENTAL", "-c", os.path.join(CSRC, "gemm.hip"), "-o", obj])
+    others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "gemm.hip"]
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
+    return out
+
+
 def build_flash_timing(verbose: bool = True) -> str:
     """Diagnostics build with the in-kernel timeline of the flash forward (-DOTTER_FLASH_TIMING) ->
     lib/libotter_hip_flashtiming.so; only tools/flash_timeline.py loads it."""
@@ -86,7 +99,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    if "--flash-timing" in sys.argv:
+    if "--experimental" in sys.argv:
+        print(build_experimental())
+    elif "--flash-timing" in sys.argv:
         print(build_flash_timing())
     elif "--diag" in sys.argv:
         print(build_diag(int(sys.argv[sys.argv.index("--diag") + 1])))

@@ -726,6 +726,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
     }  // persistent tile loop
 }
 
+#ifdef OTTER_EXPERIMENTAL  // tools-only variant (python -m otter_amd.build --experimental)
 // ------------------------------------------------------------------------------------------------------------
 // bf16 wave-specialised kernel (variant 8): 8 MFMA waves + 4 LOADER waves (768 threads, 3 waves per SIMD).
 // Why: ablations with a diagnostics build (tools/gemm_load_exp.py) showed that in every schedule above the LDS-DMA stream
@@ -844,6 +845,8 @@ __global__ __launch_bounds__(768) void gemm_bf16_ws_kernel(GemmArgs g) {
         }
     }
 }
+
+#endif  // OTTER_EXPERIMENTAL (variant 8)
 
 // ------------------------------------------------------------------------------------------------------------
 // bf16 phased kernel (variant 6): the 256x256x64 / 8-wave / LDS-DMA kernel above with the K-tile split into four
@@ -1318,6 +1321,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
 #undef RAW_BARRIER
 }
 
+#ifdef OTTER_EXPERIMENTAL  // tools-only variants (python -m otter_amd.build --experimental): the round-1/2 kernel generations that led to variant 26
 // ------------------------------------------------------------------------------------------------------------
 // bf16 multi-stage kernel (variant 4): 256x256 tile, 4 waves = ONE wave per SIMD, each wave owns 128x128 (4x4 blocks of
 // 32x32 -> 256 accumulator registers, the other half of the 512-entry unified file holds operands), K advanced in
@@ -2304,6 +2308,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
 #undef TMARK
 }
 
+#endif  // OTTER_EXPERIMENTAL (variants 4/5/12, 17, 18-23)
+
 // ------------------------------------------------------------------------------------------------------------
 // bf16 register-resident K-tile kernel on v_mfma_f32_16x16x32_bf16 (variant 26): variant 18's pipeline, LDS image and DMA
 // unchanged, the matrix instruction swapped.  Why: tools/probe/mfma_power.hip -- back-to-back MFMAs, one wave per SIMD, 256
@@ -2535,6 +2541,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         MMA(1, 6, 7); SB();                                                                                                                                                                     \
         MMA(1, 7, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
     } while (0)
+#ifdef OTTER_EXPERIMENTAL
 #define KTILE_T1(BUF, TV, DMA, NEXT)                                                                                                                                                            \
     do {                                                                                                                                                                                        \
         MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
@@ -2929,6 +2936,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         MMA(1, 7, 7); SB();                                                                                                  \
     } while (0)
 // ---- end of generated schedule ----
+#endif  // OTTER_EXPERIMENTAL (alternative placements T1-T3)
 #define KLOOP(KT)                                   \
     do {                                            \
         int t = 0;                                  \
@@ -2939,14 +2947,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         KT(0, t, false, true);                      \
         KT(1, t + 1, false, false);                 \
     } while (0)
+#ifdef OTTER_EXPERIMENTAL
         if constexpr (SCH == 0) KLOOP(KTILE_T0);
         else if constexpr (SCH == 1) KLOOP(KTILE_T1);
         else if constexpr (SCH == 2) KLOOP(KTILE_T2);
         else KLOOP(KTILE_T3);
-#undef KLOOP
 #undef KTILE_T1
 #undef KTILE_T2
 #undef KTILE_T3
+#else
+        static_assert(SCH == 0, "the alternative placements of variant 26 (27-29) are in the OTTER_EXPERIMENTAL build only");
+        KLOOP(KTILE_T0);
+#endif
+#undef KLOOP
 #undef KTILE_T0
 #undef MMA
 
@@ -3285,6 +3298,26 @@ void cfg_tiles(int cfg, int& bm, int& bn) {
     else { bm = 256; bn = 256; }
 }
 
+// Persistent grids: one workgroup per CU of THIS device (hipDeviceProp_t::multiProcessorCount, read once per process -- one
+// process drives one GPU), capped by otter_gemm_set_cu_budget: with a DP reducer live the GEMMs leave a few CUs to RCCL's
+// kernels so the all-reduce of bucket i runs beside the dgrad GEMMs of the layers below instead of waiting for the gaps
+// between launches (every persistent GEMM otherwise pins all CUs with one 512-register wave per SIMD).
+int g_cu_budget = 0;   // 0 = all
+unsigned device_cus() {
+    static unsigned n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                ? (unsigned)p.multiProcessorCount : 256u;
+    }
+    return n;
+}
+unsigned persistent_cus() {
+    const unsigned n = device_cus();
+    return (g_cu_budget > 0 && (unsigned)g_cu_budget < n) ? (unsigned)g_cu_budget : n;
+}
+
 // ---- profiling hook (bench.py roofline object) ----
 struct Prof {
     bool armed = false;
@@ -3312,7 +3345,7 @@ int launch_one(dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     // persistent grid: one resident wave of blocks (256 CUs x blocks that fit per CU), rounded to a multiple of 8
     const unsigned per_cu = (BM == 256) ? 1u : 2u;
-    unsigned pg = 256u * per_cu;
+    unsigned pg = persistent_cus() * per_cu;
     if (grid.x < pg) pg = grid.x;
     hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, WM, WN, GLDS, EPI>), dim3(pg), dim3(WM * WN * 64), smem, st, g);
     return OTTER_OK;
@@ -3326,23 +3359,26 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     if (cfg == CFG_128) return launch_one<128, 128, 2, 2, false, EPI>(grid, st, g);
     if (cfg == CFG_256) return launch_one<256, 256, 2, 4, false, EPI>(grid, st, g);
+#ifdef OTTER_EXPERIMENTAL
     if (cfg == CFG_WS) {
         static bool once = false;
         const int smem = 2 * (256 + 256) * 128;
         if (!once) { int rc = set_smem(gemm_bf16_ws_kernel<EPI>, smem); if (rc) return rc; once = true; }
-        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
         hipLaunchKernelGGL((gemm_bf16_ws_kernel<EPI>), dim3(pg), dim3(768), smem, st, g);
         return OTTER_OK;
     }
+#endif
     if (cfg == CFG_PH || cfg == CFG_PHC || cfg == CFG_PHB || cfg == CFG_PHCB || cfg == CFG_PHRB || cfg == CFG_PHLB || cfg == CFG_PHIB || cfg == CFG_PH2B || cfg == CFG_PHDB) {
         const int smem = 2 * (256 + 256) * 128;
-        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
 #define LAUNCH_PH(CNT_, BUF_)                                                                                              \
     do {                                                                                                                   \
         static bool once = false;                                                                                          \
         if (!once) { int rc = set_smem(gemm_bf16_ph_kernel<EPI, CNT_, BUF_>, smem); if (rc) return rc; once = true; }      \
         hipLaunchKernelGGL((gemm_bf16_ph_kernel<EPI, CNT_, BUF_>), dim3(pg), dim3(512), smem, st, g);                      \
     } while (0)
+#ifdef OTTER_EXPERIMENTAL
         if (cfg == CFG_PH) LAUNCH_PH(0, false);
         else if (cfg == CFG_PHC) LAUNCH_PH(1, false);
         else if (cfg == CFG_PHB) LAUNCH_PH(0, true);
@@ -3352,9 +3388,13 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         else if (cfg == CFG_PHIB) LAUNCH_PH(4, true);
         else if (cfg == CFG_PH2B) LAUNCH_PH(5, true);
         else LAUNCH_PH(6, true);
+#else
+        LAUNCH_PH(3, true);   // variant 13, the only phased schedule of the product build (pick_cfg admits no other)
+#endif
 #undef LAUNCH_PH
         return OTTER_OK;
     }
+#ifdef OTTER_EXPERIMENTAL
     if (cfg == CFG_MS4 || cfg == CFG_MS5 || cfg == CFG_MS5B) {
         const int smem = (cfg == CFG_MS4 ? 4 : 5) * 32768;
 #define LAUNCH_MS(NS_, BUF_)                                                                                               \
@@ -3371,7 +3411,7 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     }
     if (cfg == CFG_R4 || cfg == CFG_R4B || cfg == CFG_R4C || cfg == CFG_R4P || cfg == CFG_R4M || cfg == CFG_R4N) {
         const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;  // two K-tile buffers; the tail's parking buffers alias them
-        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
 #define LAUNCH_R4(SCH_, PF_)                                                                                               \
     do {                                                                                                                   \
         static bool once = false;                                                                                          \
@@ -3387,9 +3427,10 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
 #undef LAUNCH_R4
         return OTTER_OK;
     }
+#endif
     if (cfg == CFG_T4 || cfg == CFG_T4B || cfg == CFG_T4C || cfg == CFG_T4M) {
         const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;
-        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
         if (g_order & 0x10) pg = grid.x;   // diagnostics (otter_gemm_set_debug bit 13): one workgroup per tile instead of the persistent grid
 #define LAUNCH_T4(SCH_)                                                                                                    \
     do {                                                                                                                   \
@@ -3397,10 +3438,14 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         if (!once) { int rc = set_smem(gemm_bf16_t4_kernel<EPI, SCH_>, smem); if (rc) return rc; once = true; }            \
         hipLaunchKernelGGL((gemm_bf16_t4_kernel<EPI, SCH_>), dim3(pg), dim3(256), smem, st, g);                            \
     } while (0)
+#ifdef OTTER_EXPERIMENTAL
         if (cfg == CFG_T4) LAUNCH_T4(0);
         else if (cfg == CFG_T4B) LAUNCH_T4(1);
         else if (cfg == CFG_T4C) LAUNCH_T4(2);
         else LAUNCH_T4(3);
+#else
+        LAUNCH_T4(0);
+#endif
 #undef LAUNCH_T4
         return OTTER_OK;
     }
@@ -3408,18 +3453,20 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         static bool once = false;
         const int smem = 4 * 32768;  // the ring; the tail's parking buffers (4 waves x 2 stripes = 69632 B) alias it
         if (!once) { int rc = set_smem(gemm_bf16_s4_kernel<EPI>, smem); if (rc) return rc; once = true; }
-        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
         hipLaunchKernelGGL((gemm_bf16_s4_kernel<EPI>), dim3(pg), dim3(256), smem, st, g);
         return OTTER_OK;
     }
+#ifdef OTTER_EXPERIMENTAL
     if (cfg == CFG_Q4) {
         static bool once = false;
         const int smem = TAIL_LDS_BYTES;  // 4 x 32 KB ring; the tail's parking buffers (139264 B) alias it
         if (!once) { int rc = set_smem(gemm_bf16_q4_kernel<EPI>, smem); if (rc) return rc; once = true; }
-        unsigned pg = grid.x < 256u ? grid.x : 256u;
+        unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
         hipLaunchKernelGGL((gemm_bf16_q4_kernel<EPI>), dim3(pg), dim3(256), smem, st, g);
         return OTTER_OK;
     }
+#endif
     return launch_one<256, 256, 2, 4, true, EPI>(grid, st, g);
 }
 
@@ -3449,8 +3496,27 @@ int otter_device_check(void) {
     return p.multiProcessorCount;
 }
 
+int otter_gemm_set_cu_budget(int cus) {
+    if (cus < 0) OTTER_FAIL(OTTER_ERR_ARG, "gemm cu budget %d", cus);
+    g_cu_budget = (cus > 0 && cus < 8) ? 8 : cus;   // at least one workgroup per XCD
+    return (int)persistent_cus();
+}
+
+int otter_gemm_variant_available(int variant) {
+    if (variant < 0 || variant > 29 || variant == 24) return 0;
+#ifdef OTTER_EXPERIMENTAL
+    return 1;
+#else
+    // product build: auto (0), the generic 128^2 / 256^2 kernels (1-3), the phased fallback for K % 128 != 0 (13), the small-grid ring
+    // (25) and the default (26); every other schedule is compiled into the tools-only experimental library
+    return variant <= 3 || variant == CFG_PHLB || variant == CFG_S4 || variant == CFG_T4;
+#endif
+}
+
 int otter_gemm_set_variant(int variant) {
     if (variant < 0 || variant > 29) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (!otter_gemm_variant_available(variant))
+        OTTER_FAIL(OTTER_ERR_UNSUPPORTED, "gemm variant %d is in the experimental build only (python -m otter_amd.build --experimental)", variant);
     g_variant = variant;
     return OTTER_OK;
 }

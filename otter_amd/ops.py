@@ -559,6 +559,20 @@ def set_gemm_variant(v: int):
     K.check(K.lib().otter_gemm_set_variant(int(v)), "gemm_set_variant")
 
 
+def gemm_variant_available(v: int) -> bool:
+    """True when schedule `v` is compiled into the loaded library (the product build carries 0-3, 13, 25, 26; the rest live in the
+    tools-only experimental build: OTTER_LIB_PATH=otter_amd/lib/libotter_hip_experimental.so)."""
+    return bool(K.lib().otter_gemm_variant_available(int(v)))
+
+
+def set_gemm_cu_budget(cus: int) -> int:
+    """Cap the persistent GEMM grids at `cus` workgroups (0 = all CUs); returns the grid size in effect."""
+    n = K.lib().otter_gemm_set_cu_budget(int(cus))
+    if n < 0:
+        K.check(n, "gemm_set_cu_budget")
+    return int(n)
+
+
 def prof_arm_gemm(M, N, Kd, max_events=4096):
     K.check(K.lib().otter_prof_arm_gemm(M, N, Kd, max_events), "prof_arm")
 

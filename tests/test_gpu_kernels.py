@@ -7,6 +7,8 @@ Tolerances (stated per the brief):
                 fp32 accumulation order + one bf16 rounding of the output: 1e-2 relative-to-max for bf16 outputs,
                 1e-4 for fp32 outputs of bf16-operand GEMMs.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -231,10 +233,21 @@ def test_llama_ops_golden(ops):
 # GEMM (all variants, all epilogues)
 # ----------------------------------------------------------------------------------------------------------------------
 
+# The product library carries the schedules pick_cfg can choose (1-3, 13, 25, 26); the kernel generations that led to them (rounds
+# 1-2) are compiled into the tools-only experimental library and are tested only when the suite is pointed at it
+# (OTTER_LIB_PATH=otter_amd/lib/libotter_hip_experimental.so python -m pytest tests/test_gpu_kernels.py -m gpu -k gemm).
+LIVE_VARIANTS = [1, 2, 3, 13, 25, 26]
+_EXPERIMENTAL = os.environ.get("OTTER_LIB_PATH", "").endswith("experimental.so")
+
+
+def variants(*cands):
+    return [v for v in cands if v in LIVE_VARIANTS or _EXPERIMENTAL]
+
+
 GEMM_SHAPES = [(48, 128, 48), (200, 136, 328), (257, 512, 64), (64, 384, 1024), (520, 264, 200), (300, 520, 256), (513, 260, 128)]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26])
+@pytest.mark.parametrize("variant", variants(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26))
 @pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
 def test_gemm_bf16_store(ops, variant, M, N, Kd):
     ops.set_gemm_variant(variant)
@@ -262,7 +275,7 @@ def test_gemm_f32_store(ops, M, N, Kd):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", [1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26])
+@pytest.mark.parametrize("variant", variants(1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26))
 def test_gemm_epilogues(ops, dt, variant):
     from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
 
@@ -310,7 +323,7 @@ def test_gemm_epilogues(ops, dt, variant):
         ops.set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("variant", [17, 18, 19, 20, 21, 22, 23, 25, 26])
+@pytest.mark.parametrize("variant", variants(17, 18, 19, 20, 21, 22, 23, 25, 26))
 @pytest.mark.parametrize("out_dt", ["bf16", "f32"])
 def test_gemm_full_tile_fast_tail(ops, variant, out_dt):
     """The one-wave-per-SIMD kernels take an unrolled, double-buffered tail on full in-bounds tiles: every epilogue kind and
@@ -360,7 +373,7 @@ def test_gemm_full_tile_fast_tail(ops, variant, out_dt):
     assert relmax(host(mine["gelu_pre"]), ref) < tol
 
 
-@pytest.mark.parametrize("variant", [18, 21, 22, 23])
+@pytest.mark.parametrize("variant", variants(18, 21, 22, 23, 26))
 def test_gemm_persistent_blocks_with_several_tiles(ops, variant):
     """More tiles than CUs (17 x 16 = 272 tiles of 256 x 256, K = 384 -> the tail-trip-only K loop of nk = 6): the persistent blocks
     walk 2 tiles each for 16 of them, which is where variant 21 prefetches the next tile's first K-tile under the tail.  Bit-exact
@@ -384,6 +397,82 @@ def test_gemm_persistent_blocks_with_several_tiles(ops, variant):
     assert relmax(host(outs[variant][0][:300]), ref) < 1e-2
 
 
+BENCH_GEMMS = [
+    # (M, N, K, kind, out dtype): every launch shape of the gated cross-attention block at config C2 (B*T = 4096 tokens, D = 4096,
+    # FFN 16384, inner 512) as pick_cfg dispatches it -- T4 (variant 26) for the FFN shapes, S4 (variant 25) for the projections
+    (4096, 16384, 4096, "gelu", "bf16"),        # FF1 forward: h = gelu(f W1^T), u stored beside it
+    (4096, 4096, 16384, "res", "f32"),          # FF2 forward: y = (h W2^T) tanh(g) + x1, fp32 stream
+    (4096, 16384, 4096, "gate_bwd", "bf16"),    # dU = (dy W2) tanh(g) gelu'(u)
+    (4096, 4096, 16384, "store", "bf16"),       # df = dU W1
+    (16384, 4096, 4096, "store_gate", "f32"),   # dW1 = dU^T f        (fp32 weight gradient)
+    (4096, 16384, 4096, "store_gate", "f32"),   # dW2 = tanh(g) dy^T h (fp32 weight gradient)
+    (4096, 512, 4096, "store", "bf16"),         # to_q
+    (4096, 4096, 512, "res", "f32"),            # to_out + gate + residual
+    (512, 4096, 4096, "store_gate", "f32"),     # dWq
+    (4096, 512, 4096, "store_gate", "f32"),     # dWo
+]
+
+
+@pytest.mark.parametrize("M,N,Kd,kind,out_dt", BENCH_GEMMS)
+def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt):
+    """the kernels the benchmark times, at the benchmark's shapes, with the fused tails and the fp32-output
+    weight-gradient form -- default dispatch (variant 0).  A full fp64 product of 4096 x 16384 x 4096 is too slow for the host, so:
+    (a) 96 sampled rows and 96 sampled columns (incl. first / last of every 256-tile edge) against the fp64 product of those rows /
+    columns; (b) a checksum over EVERY element through linearity: C 1 = A (B^T 1) for the plain store (fp64 on the host, O(MK + NK))."""
+    from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
+
+    r = rng(M // 7 + N + Kd)
+    A = bf16_round(r.standard_normal((M, Kd)).astype(np.float32) * 0.25)
+    B = bf16_round(r.standard_normal((N, Kd)).astype(np.float32) * 0.25)
+    dA, dB = to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16)
+    odt = torch.bfloat16 if out_dt == "bf16" else torch.float32
+    gate = np.array([0.6], np.float32)
+    s = float(np.tanh(0.6))
+    rows = np.unique(np.concatenate([[0, 255, 256, M - 257, M - 1], r.integers(0, M, 91)]))
+    cols = np.unique(np.concatenate([[0, 255, 256, N - 257, N - 1], r.integers(0, N, 91)]))
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    acc_r = A64[rows] @ B64.T              # [rows, N]
+    acc_c = A64 @ B64[cols].T              # [M, cols]
+    tol = 1e-2 if out_dt == "bf16" else 2e-4
+
+    def check(C, f, tol_=tol):
+        Ch = host(C)
+        assert relmax(Ch[rows], f(acc_r, rows, slice(None))) < tol_
+        assert relmax(Ch[:, cols], f(acc_c, slice(None), cols)) < tol_
+
+    if kind == "store":
+        C = ops.gemm_nt(dA, dB, out_dtype=odt)
+        check(C, lambda a, i, j: a)
+    elif kind == "store_gate":
+        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_STORE, gate=to_dev(gate))
+        check(C, lambda a, i, j: a * s)
+        # checksum of every element: row sums of C == s * A (sum_n B[n, :])
+        rs = host(C).astype(np.float64).sum(1)
+        want = s * (A64 @ B64.sum(0))
+        assert np.abs(rs - want).max() < 1e-3 * np.abs(want).max() + 1e-3 * np.sqrt(N)
+    elif kind == "gelu":
+        C2 = torch.empty((M, N), dtype=odt, device=DEV)
+        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GELU, C2=C2)
+        check(C2, lambda a, i, j: a)
+        check(C, lambda a, i, j: O.gelu_fwd(a))
+    elif kind == "res":
+        R = r.standard_normal((M, N)).astype(np.float32)
+        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_SCALE_RES, gate=to_dev(gate), R=to_dev(R))
+        check(C, lambda a, i, j: a * s + R[i, j].astype(np.float64))
+    else:
+        aux = bf16_round(r.standard_normal((M, N)).astype(np.float32))
+        part = torch.zeros(ops.gemm_num_partials(M, N, torch.bfloat16), dtype=torch.float32, device=DEV)
+        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GATE_BWD, gate=to_dev(gate), aux=to_dev(aux, torch.bfloat16), aux_gelu=True, partial=part)
+        check(C, lambda a, i, j: s * a * O.gelu_grad(aux[i, j].astype(np.float64)))
+        # the gate gradient = (1 - s^2) sum(acc * gelu(aux)) over EVERY element: against an independent fp32 product (torch / rocBLAS on
+        # the same device, fp64 reduction) -- the per-tile partials + reduce kernel see all 64 M accumulators
+        dg = float(ops.reduce_partials(part, gate=to_dev(gate))[0])
+        acc_t = torch.matmul(dA.float(), dB.float().t())
+        want = float((acc_t.double() * torch.nn.functional.gelu(to_dev(aux).double())).sum()) * (1 - s * s)
+        scale = float((acc_t.double() * torch.nn.functional.gelu(to_dev(aux).double())).abs().sum()) * (1 - s * s)
+        assert abs(dg - want) < 1e-5 * scale + 1e-3
+
+
 def test_gemm_big_variants_agree(ops):
     """All three bf16 schedules produce the same numbers on the FFN shape class (256-multiple tiles, K=1024)."""
     r = rng(3)
@@ -392,7 +481,7 @@ def test_gemm_big_variants_agree(ops):
     B = to_dev(r.standard_normal((N, Kd)), torch.bfloat16)
     ref = host(A).astype(np.float64) @ host(B).astype(np.float64).T
     outs = []
-    for v in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26):
+    for v in variants(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26):
         ops.set_gemm_variant(v)
         outs.append(ops.gemm_nt(A, B, out_dtype=torch.float32))
     ops.set_gemm_variant(0)
@@ -739,6 +828,71 @@ def test_sqrelu_and_scatter_rows(ops):
     for wdt, pdt in ((torch.float32, torch.bfloat16), (torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)):
         out = ops.scatter_rows(to_dev(word, wdt), to_dev(patch, pdt), torch.from_numpy(idx).to(DEV))
         assert relmax(host(out), ref) < (1e-6 if wdt == torch.float32 else 8e-3)
+
+
+def test_scatter_rows_out_of_range_index_is_never_dereferenced(ops):
+    """an index >= P must not read another sample's rows (or past the buffer): the kernel writes NaN for it (the host
+    wrapper of the module raises IndexError before launching -- tests/test_fuyu_host.py); every other row is untouched."""
+    r = rng(68)
+    B, S, P, D = 2, 9, 4, 64
+    word = r.standard_normal((B, S, D)).astype(np.float32)
+    patch = r.standard_normal((B, P, D)).astype(np.float32)
+    idx = np.full((B, S), -1, np.int64)
+    idx[0, 1:4] = [0, 3, 4]          # 4 == P: out of range (would alias patch[1, 0] without the check)
+    idx[1, 8] = 1 << 40              # far out of range
+    out = host(ops.scatter_rows(to_dev(word), to_dev(patch), torch.from_numpy(idx).to(DEV)))
+    assert np.isnan(out[0, 3]).all() and np.isnan(out[1, 8]).all()
+    assert np.array_equal(out[0, 1], patch[0, 0]) and np.array_equal(out[0, 2], patch[0, 3]) and np.array_equal(out[0, 0], word[0, 0])
+    assert np.array_equal(out[1, :8], word[1, :8])
+
+
+def test_gemm_cu_budget_and_variant_availability(ops):
+    """otter_gemm_set_cu_budget: the persistent kernels run on fewer workgroups (CUs left to a concurrent RCCL kernel) with identical
+    results; the product library rejects the experimental schedules loudly."""
+    from otter_amd import _capi
+
+    r = rng(91)
+    M, N, Kd = 4096, 4096, 512            # 256 tiles of 256^2 (the T4 kernel) walked by 240 / 8 persistent workgroups
+    A = to_dev(bf16_round(r.standard_normal((M, Kd)) * 0.3), torch.bfloat16)
+    B = to_dev(bf16_round(r.standard_normal((N, Kd)) * 0.3), torch.bfloat16)
+    base = ops.gemm_nt(A, B, out_dtype=torch.float32)
+    try:
+        for budget in (240, 8, 1):
+            eff = ops.set_gemm_cu_budget(budget)
+            assert eff == max(budget, 8)
+            assert torch.equal(ops.gemm_nt(A, B, out_dtype=torch.float32), base), budget
+            # small-grid ring kernel and the 128^2 kernel as well
+            assert torch.equal(ops.gemm_nt(A[:512], B[:512], out_dtype=torch.float32), base[:512, :512])
+    finally:
+        total = ops.set_gemm_cu_budget(0)
+    assert total == _capi.lib().otter_device_check()
+    assert all(ops.gemm_variant_available(v) for v in LIVE_VARIANTS) and not ops.gemm_variant_available(24)
+    if not _EXPERIMENTAL:
+        assert not ops.gemm_variant_available(18)
+        with pytest.raises(_capi.OtterHipError, match="experimental build"):
+            ops.set_gemm_variant(18)
+
+
+def test_decode_attention_at_the_lds_limit(ops):
+    """Sk = 16384 needs 64 KiB of dynamic LDS (above the default allowance): the launcher opts in; one step beyond is
+    refused with a message, not a launch failure."""
+    from otter_amd import _capi
+
+    r = rng(72)
+    B, H, d = 1, 2, 128
+    for Sk in (16384, 8193):
+        q = bf16_round(r.standard_normal((B, H, d)))
+        k = bf16_round(r.standard_normal((B, H, Sk, d)) * 0.5)
+        v = bf16_round(r.standard_normal((B, H, Sk, d)))
+        o = ops.decode_attn(to_dev(q, torch.bfloat16), to_dev(k, torch.bfloat16), to_dev(v, torch.bfloat16), None, None, d ** -0.5)
+        sc = np.einsum("bhd,bhsd->bhs", q.astype(np.float64), k.astype(np.float64)) * d ** -0.5
+        p = np.exp(sc - sc.max(-1, keepdims=True))
+        p /= p.sum(-1, keepdims=True)
+        ref = np.einsum("bhs,bhsd->bhd", p, v.astype(np.float64))
+        assert relmax(host(o), ref) < 2e-2, Sk
+    big = torch.zeros((1, 1, 16392, d), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_capi.OtterHipError, match="exceeds the LDS score buffer"):
+        ops.decode_attn(torch.zeros((1, 1, d), dtype=torch.bfloat16, device=DEV), big, big, None, None, 1.0)
 
 
 @pytest.mark.parametrize("layout", ["mpt", "llama"])
