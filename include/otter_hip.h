@@ -139,6 +139,17 @@ typedef struct {
 int64_t otter_gemm_num_partials(int64_t M, int64_t N, int ab_dtype);
 int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,
                   int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream);
+/* C[M,N] = epilogue(op(A) . op(B)^T) with K-MAJOR operands (round 3): with a_kmajor != 0, A is handed over as [K rows][M columns]
+ * row-major (row stride lda), i.e. the reduction index is the ROW index; likewise B as [K][N] with b_kmajor.  These are the
+ * layouts the backward products of an nn.Linear have their operands in -- dW[out,in] = dy^T x (both K-major: K = token rows;
+ * autograd's `grad_output.t().mm(input)`, the backward of every nn.Linear at otter/modeling_otter.py:140-147,254-256,366-368) and
+ * dx = dy W with W as stored [out,in] (B K-major) -- so no operand is transposed in HBM first.  Same epilogues, dtypes and stream
+ * semantics as otter_gemm_nt (which is this call with both flags 0).  Only shapes for which otter_gemm_kmajor_supported returns 1
+ * are accepted (bf16, K % 128 == 0, >= 192 output tiles of 256 x 256, M / N / leading dimensions multiples of 8, operands < 4 GB);
+ * the host transposes (otter_transpose) and calls otter_gemm_nt otherwise. */
+int otter_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc, int64_t M,
+               int64_t N, int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream);
+int otter_gemm_kmajor_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int a_kmajor, int b_kmajor, int ab_dtype);
 /* selects the bf16 kernel schedule: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 register-staged,
  * 3 = 256x256 direct-to-LDS (global_load_lds).  Process-wide; for A/B measurements. */
 int otter_gemm_set_variant(int variant);

@@ -75,6 +75,8 @@ SIGNATURES = {
     "otter_rmsnorm_bwd_ex": (_int, [_vp, _int, _vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp, _int, _vp, _i64, _i64, _vp]),
     "otter_gemm_num_partials": (_i64, [_i64, _i64, _int]),
     "otter_gemm_nt": (_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _int, _int, C.POINTER(EpilogueArgs), _vp]),
+    "otter_gemm": (_int, [_vp, _i64, _int, _vp, _i64, _int, _vp, _i64, _i64, _i64, _i64, _int, _int, C.POINTER(EpilogueArgs), _vp]),
+    "otter_gemm_kmajor_supported": (_int, [_i64, _i64, _i64, _i64, _i64, _int, _int, _int]),
     "otter_gemm_set_variant": (_int, [_int]),
     "otter_gemm_variant_available": (_int, [_int]),
     "otter_gemm_set_cu_budget": (_int, [_int]),

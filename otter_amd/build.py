@@ -14,6 +14,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libotter_hip.so")
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "flash.hip", "optim.hip", "attn_mfma.hip", "loss.hip", "fuyu.hip", "decode.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-unused-value"]
+# gemm.hip: the K-major instantiations of variant 26 keep their accumulators in explicit AGPRs behind asm MFMAs; hipcc must not use the
+# AGPR half as spill space of its own there (it would, between the K loop and the tail's read-back: measured as wrong blocks)
+EXTRA = {"gemm.hip": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
 
 
 def hipcc() -> str:
@@ -38,7 +41,7 @@ def build_diag(mask: int, verbose: bool = True) -> str:
     cc = hipcc()
     obj = os.path.join(LIBDIR, "gemm_diag%d.o" % mask)
     out = os.path.join(LIBDIR, "libotter_hip_diag%d.so" % mask)
-    subprocess.check_call([cc, *FLAGS, "-DOTTER_DIAG=%d" % mask, "-c", os.path.join(CSRC, "gemm.hip"), "-o", obj])
+    subprocess.check_call([cc, *FLAGS, *EXTRA["gemm.hip"], "-DOTTER_DIAG=%d" % mask, "-c", os.path.join(CSRC, "gemm.hip"), "-o", obj])
     others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "gemm.hip"]
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
     return out
@@ -51,7 +54,19 @@ def build_experimental(verbose: bool = True) -> str:
     cc = hipcc()
     obj = os.path.join(LIBDIR, "gemm_experimental.o")
     out = os.path.join(LIBDIR, "libotter_hip_experimental.so")
-    subprocess.check_call([cc, *FLAGS, "-DOTTER_EXPERIMENTAL", "-c", os.path.join(CSRC, "gemm.hip"), "-o", obj])
+    subprocess.check_call([cc, *FLAGS, *EXTRA["gemm.hip"], "-DOTTER_EXPERIMENTAL", "-c", os.path.join(CSRC, "gemm.hip"), "-o", obj])
+    others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "gemm.hip"]
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
+    return out
+
+
+def build_gemm_define(define: str, suffix: str, verbose: bool = True) -> str:
+    """Debug build of gemm.hip with one extra -D (e.g. OTTER_KMDBG=1) -> lib/libotter_hip_<suffix>.so (tools only, via OTTER_LIB_PATH)."""
+    build(verbose=verbose)
+    cc = hipcc()
+    obj = os.path.join(LIBDIR, "gemm_%s.o" % suffix)
+    out = os.path.join(LIBDIR, "libotter_hip_%s.so" % suffix)
+    subprocess.check_call([cc, *FLAGS, *EXTRA["gemm.hip"], "-D" + define, "-c", os.path.join(CSRC, "gemm.hip"), "-o", obj])
     others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "gemm.hip"]
     subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
     return out
@@ -83,7 +98,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src, obj = pair
         if not force and _newer(obj, [src] + hdrs):
             return obj
-        cmd = [cc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [cc, *FLAGS, *EXTRA.get(os.path.basename(src), []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -99,7 +114,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    if "--experimental" in sys.argv:
+    if "--define" in sys.argv:
+        i = sys.argv.index("--define")
+        print(build_gemm_define(sys.argv[i + 1], sys.argv[i + 2]))
+    elif "--experimental" in sys.argv:
         print(build_experimental())
     elif "--flash-timing" in sys.argv:
         print(build_flash_timing())

@@ -46,6 +46,7 @@ struct GemmArgs {
     int dbg;  // diagnostics only (otter_gemm_set_debug): bit0 = skip K-loop global loads, bit1 = skip MFMAs
     int order;  // tile order override (diagnostics, see tile_of_block)
     int wide;  // bf16 output and every tensor the fused tail touches allows 8-element accesses (N, ldc, ldc2, ldr, ldaux % 8 == 0)
+    int ta, tb;  // operand A / B is K-major ([K rows][M or N columns]); variant 26 only (otter_gemm)
 };
 
 __device__ __forceinline__ void load4(const void* p, int64_t idx, int dt, float (&v)[4]) {
@@ -479,6 +480,37 @@ __device__ __forceinline__ void park_stripe(float* __restrict__ blk, const f32x4
             *reinterpret_cast<float4*>(blk + (16 * a + (lane & 15)) * EPI_LD + 16 * b + 4 * (lane >> 4)) = make_float4(v[0], v[1], v[2], v[3]);
         }
 }
+
+// Accumulators held in EXPLICIT AGPRs (K-major instantiations of variant 26: block (mi, ni) = a[4 (8 mi + ni) .. + 3], written by asm MFMAs):
+// parked straight out of the AGPR half with ds_write_b128 (DS instructions take AGPR data on gfx90a+), same LDS image as the overload
+// above -- the values never become C++ values, so hipcc has nothing to copy, split or spill.  The caller has waited out the MFMA -> read
+// hazard.  LDS operations of a wave complete in order: the tail's compiler-visible reads of `blk` that follow see these writes.
+struct AgprAcc {};
+#define PARK_AGPR_BLOCK(A_, B_, MI_, NI_)                                                                                             \
+    asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3" : : "v"(addr), "n"(((MI_) * 8 + (NI_)) * 4), "n"(((MI_) * 8 + (NI_)) * 4 + 3), \
+                 "n"(((A_) * 16 * EPI_LD + (B_) * 16) * 4) : "memory")
+#define PARK_AGPR_STRIPE(ST_)                                                                                                          \
+    do {                                                                                                                              \
+        PARK_AGPR_BLOCK(0, 0, 2 * ((ST_) >> 1), 4 * ((ST_) & 1)); PARK_AGPR_BLOCK(0, 1, 2 * ((ST_) >> 1), 4 * ((ST_) & 1) + 1);         \
+        PARK_AGPR_BLOCK(0, 2, 2 * ((ST_) >> 1), 4 * ((ST_) & 1) + 2); PARK_AGPR_BLOCK(0, 3, 2 * ((ST_) >> 1), 4 * ((ST_) & 1) + 3);     \
+        PARK_AGPR_BLOCK(1, 0, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1)); PARK_AGPR_BLOCK(1, 1, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1) + 1); \
+        PARK_AGPR_BLOCK(1, 2, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1) + 2); PARK_AGPR_BLOCK(1, 3, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1) + 3); \
+    } while (0)
+__device__ __forceinline__ void park_stripe(float* __restrict__ blk, const AgprAcc&, int st, int lane) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)(blk + (lane & 15) * EPI_LD + 4 * (lane >> 4));
+    switch (st) {   // st is a constant after unrolling: one case survives
+        case 0: PARK_AGPR_STRIPE(0); break;
+        case 1: PARK_AGPR_STRIPE(1); break;
+        case 2: PARK_AGPR_STRIPE(2); break;
+        case 3: PARK_AGPR_STRIPE(3); break;
+        case 4: PARK_AGPR_STRIPE(4); break;
+        case 5: PARK_AGPR_STRIPE(5); break;
+        case 6: PARK_AGPR_STRIPE(6); break;
+        default: PARK_AGPR_STRIPE(7); break;
+    }
+}
+#undef PARK_AGPR_STRIPE
+#undef PARK_AGPR_BLOCK
 
 template <int EPI, bool CBF16, bool INBF16, int NS, typename ACC>
 __device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, const ACC& acc, float* __restrict__ blk4 /* NS stripes */,
@@ -2322,10 +2354,155 @@ __global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
 // row parities = 16 distinct bank groups with the same swizzle as the 32-row fragments.
 // Schedule generated by tools/gen/gemm_t4_schedule.py.  Requires K % 128 == 0 and operands spanning < 4 GB.
 // ------------------------------------------------------------------------------------------------------------
-template <int EPI, int SCH>
+// K-major operands (TA / TB; round 3): an operand may be handed over as [K rows][M or N columns] row-major -- the layout every
+// BACKWARD product of a Linear has one or both operands in (dW = dy^T x: both; dx = dy W with W as stored: B) -- instead of the
+// K-contiguous rows of the forward.  Rounds 1-2 produced the K-contiguous form with a transpose kernel per operand (2.7 ms per
+// step) and kept a transposed bf16 shadow of every trainable weight (1.2 ms per step to rebuild).  Here the K-tile of such an
+// operand lands in LDS as it lies in HBM -- [64 k][256 m], 512-byte rows, each DMA instruction two whole rows = eight whole cache
+// lines -- and the MFMA fragment (lane (r, g): row m = 16 i + r, k = 32 ks + 8 g .. + 7) is gathered by two
+// ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 m] block, lane r supplying row (r >> 2), columns 4 (r & 3) .. + 3, and
+// receiving column r of it.  Same registers, same MFMA operand order, same LDS bytes as the K-contiguous form; the schedule
+// slot of a fragment read holds two LDS instructions and one v_xad_u32.  Bank conflicts: one pass of the instruction serves
+// lanes 0-31 = 8 k-rows x 32 bytes, all at the same column window of 512-byte rows, i.e. the same 8 banks; the 32-byte column
+// blocks are therefore XOR-swizzled within each 256-byte half row by f(k) = (k & 3) | ((k >> 3) & 1) << 2 (the 8 rows of a
+// pass get 8 distinct blocks), applied on the DMA SOURCE offset as everywhere else.
+// LDS-DMA issued from inline asm (K-major instantiations).  hipcc's wait-count pass cannot disambiguate the transpose-read intrinsic from a
+// pending builtin LDS-DMA and puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that follows a DMA issue -- i.e. it drains
+// the two-K-tile prefetch twice per K-tile (measured: SQ_WAIT_ANY 23 M -> 126 M wave-cycles per launch, 382 -> 562 us).  Issued from asm
+// the DMA is invisible to that pass; completion is counted by the schedule's own s_waitcnt vmcnt(N) + s_barrier (as in csrc/flash.hip).
+__device__ __forceinline__ u32x4_t gemm_rsrc4(const void* p, uint32_t bytes) {
+    const uint64_t pa = (uint64_t)p;
+    u32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)pa);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void gemm_dma16_asm(u32x4_t r, unsigned lds, uint32_t voff, uint32_t soff) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+// Address of a transpose read: k-row, half row, swizzled block and the lane's 8 bytes occupy DISJOINT bit fields of the LDS
+// offset (bits 9-13 | 8 | 5-7 | 3-4; the +4 rows of the second read, the k-step, the operand region and the buffer are higher or
+// free bits), so  row*512 + half*256 + ((i ^ f) * 32) + 8 (r & 3)  ==  lane_const ^ (i * 32): ONE v_xor_b32 with a literal per
+// fragment, everything else rides in the instruction's immediate offset.  The xor is an asm volatile on purpose: its 28 possible
+// values per lane are loop invariant, hipcc hoists them out of the K loop, and the kernel (256 accumulator + 128 fragment registers)
+// then spills 80-130 registers to scratch.
+template <int I>
+__device__ __forceinline__ bf16x8_t ldf_tr(const char* __restrict__ smem, int lane_const, int koff) {
+    typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
+    typedef short s16x8_t_ __attribute__((ext_vector_type(8)));
+    int a = lane_const;
+    if constexpr (I != 0) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a) : "n"(I * 32), "v"(lane_const));
+    const char* p = smem + a + koff;
+    const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p));
+    const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p + 2048));
+    const s16x8_t_ r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+// run-time block index (the prologue's unrolled loop)
+__device__ __forceinline__ bf16x8_t ldf_tr_rt(const char* __restrict__ smem, int lane_const, int koff, int i) {
+    typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
+    typedef short s16x8_t_ __attribute__((ext_vector_type(8)));
+    int a;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a) : "s"(i * 32), "v"(lane_const));
+    const char* p = smem + a + koff;
+    const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p));
+    const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p + 2048));
+    const s16x8_t_ r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+
+// K-major instantiations keep the 64 accumulator blocks in EXPLICIT AGPRs: block (mi, ni) = a[4 (8 mi + ni) .. + 3].  Each asm MFMA names
+// its registers and lists them as clobbers (AC_mi_ni), so hipcc accounts for the whole AGPR half and keeps nothing of its own there across
+// a K-tile; it never sees a value it could copy or split (with an "+a" operand it did: v_accvgpr_mov around the MFMAs of the peeled last
+// K-tiles, no wait states, elements 0 and 3 of every block wrong).
+#define AC_0_0 "a0", "a1", "a2", "a3"
+#define AC_0_1 "a4", "a5", "a6", "a7"
+#define AC_0_2 "a8", "a9", "a10", "a11"
+#define AC_0_3 "a12", "a13", "a14", "a15"
+#define AC_0_4 "a16", "a17", "a18", "a19"
+#define AC_0_5 "a20", "a21", "a22", "a23"
+#define AC_0_6 "a24", "a25", "a26", "a27"
+#define AC_0_7 "a28", "a29", "a30", "a31"
+#define AC_1_0 "a32", "a33", "a34", "a35"
+#define AC_1_1 "a36", "a37", "a38", "a39"
+#define AC_1_2 "a40", "a41", "a42", "a43"
+#define AC_1_3 "a44", "a45", "a46", "a47"
+#define AC_1_4 "a48", "a49", "a50", "a51"
+#define AC_1_5 "a52", "a53", "a54", "a55"
+#define AC_1_6 "a56", "a57", "a58", "a59"
+#define AC_1_7 "a60", "a61", "a62", "a63"
+#define AC_2_0 "a64", "a65", "a66", "a67"
+#define AC_2_1 "a68", "a69", "a70", "a71"
+#define AC_2_2 "a72", "a73", "a74", "a75"
+#define AC_2_3 "a76", "a77", "a78", "a79"
+#define AC_2_4 "a80", "a81", "a82", "a83"
+#define AC_2_5 "a84", "a85", "a86", "a87"
+#define AC_2_6 "a88", "a89", "a90", "a91"
+#define AC_2_7 "a92", "a93", "a94", "a95"
+#define AC_3_0 "a96", "a97", "a98", "a99"
+#define AC_3_1 "a100", "a101", "a102", "a103"
+#define AC_3_2 "a104", "a105", "a106", "a107"
+#define AC_3_3 "a108", "a109", "a110", "a111"
+#define AC_3_4 "a112", "a113", "a114", "a115"
+#define AC_3_5 "a116", "a117", "a118", "a119"
+#define AC_3_6 "a120", "a121", "a122", "a123"
+#define AC_3_7 "a124", "a125", "a126", "a127"
+#define AC_4_0 "a128", "a129", "a130", "a131"
+#define AC_4_1 "a132", "a133", "a134", "a135"
+#define AC_4_2 "a136", "a137", "a138", "a139"
+#define AC_4_3 "a140", "a141", "a142", "a143"
+#define AC_4_4 "a144", "a145", "a146", "a147"
+#define AC_4_5 "a148", "a149", "a150", "a151"
+#define AC_4_6 "a152", "a153", "a154", "a155"
+#define AC_4_7 "a156", "a157", "a158", "a159"
+#define AC_5_0 "a160", "a161", "a162", "a163"
+#define AC_5_1 "a164", "a165", "a166", "a167"
+#define AC_5_2 "a168", "a169", "a170", "a171"
+#define AC_5_3 "a172", "a173", "a174", "a175"
+#define AC_5_4 "a176", "a177", "a178", "a179"
+#define AC_5_5 "a180", "a181", "a182", "a183"
+#define AC_5_6 "a184", "a185", "a186", "a187"
+#define AC_5_7 "a188", "a189", "a190", "a191"
+#define AC_6_0 "a192", "a193", "a194", "a195"
+#define AC_6_1 "a196", "a197", "a198", "a199"
+#define AC_6_2 "a200", "a201", "a202", "a203"
+#define AC_6_3 "a204", "a205", "a206", "a207"
+#define AC_6_4 "a208", "a209", "a210", "a211"
+#define AC_6_5 "a212", "a213", "a214", "a215"
+#define AC_6_6 "a216", "a217", "a218", "a219"
+#define AC_6_7 "a220", "a221", "a222", "a223"
+#define AC_7_0 "a224", "a225", "a226", "a227"
+#define AC_7_1 "a228", "a229", "a230", "a231"
+#define AC_7_2 "a232", "a233", "a234", "a235"
+#define AC_7_3 "a236", "a237", "a238", "a239"
+#define AC_7_4 "a240", "a241", "a242", "a243"
+#define AC_7_5 "a244", "a245", "a246", "a247"
+#define AC_7_6 "a248", "a249", "a250", "a251"
+#define AC_7_7 "a252", "a253", "a254", "a255"
+#define AC_ROW(MI) AC_##MI##_0, AC_##MI##_1, AC_##MI##_2, AC_##MI##_3, AC_##MI##_4, AC_##MI##_5, AC_##MI##_6, AC_##MI##_7
+// zero one row of blocks (32 registers)
+#define ACC_ZERO_ROW(MI)                                                                                                   \
+    asm volatile(".irp r," ACC_IRP_##MI "\n\tv_accvgpr_write_b32 a\\r, 0\n\t.endr" ::: AC_ROW(MI))
+#define ACC_IRP_0 "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31"
+#define ACC_IRP_1 "32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63"
+#define ACC_IRP_2 "64,65,66,67,68,69,70,71,72,73,74,75,76,77,78,79,80,81,82,83,84,85,86,87,88,89,90,91,92,93,94,95"
+#define ACC_IRP_3 "96,97,98,99,100,101,102,103,104,105,106,107,108,109,110,111,112,113,114,115,116,117,118,119,120,121,122,123,124,125,126,127"
+#define ACC_IRP_4 "128,129,130,131,132,133,134,135,136,137,138,139,140,141,142,143,144,145,146,147,148,149,150,151,152,153,154,155,156,157,158,159"
+#define ACC_IRP_5 "160,161,162,163,164,165,166,167,168,169,170,171,172,173,174,175,176,177,178,179,180,181,182,183,184,185,186,187,188,189,190,191"
+#define ACC_IRP_6 "192,193,194,195,196,197,198,199,200,201,202,203,204,205,206,207,208,209,210,211,212,213,214,215,216,217,218,219,220,221,222,223"
+#define ACC_IRP_7 "224,225,226,227,228,229,230,231,232,233,234,235,236,237,238,239,240,241,242,243,244,245,246,247,248,249,250,251,252,253,254,255"
+#ifndef OTTER_KMDBG
+#define OTTER_KMDBG 0   // debug builds only (python -m otter_amd.build --define OTTER_KMDBG=n sfx): 1 = builtin MFMA, 2 = builtin LDS-DMA
+#endif
+template <int EPI, int SCH, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, NT = 256;
-    constexpr int TILE = (BM + BN) * 128;  // 64 KB: [256 A rows ; 256 B rows] x 128 B
+    constexpr int TILE = (BM + BN) * 128;  // 64 KB: [256 A rows ; 256 B rows] x 128 B  (K-major operand: [64 k][256 m] x 2 B, same 32 KB)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2334,10 +2511,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     const bf16_t* __restrict__ B = (const bf16_t*)g.B;
     const int nk = (int)(g.K >> 6);  // K-tiles (host guarantees nk even, nk >= 2)
     const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
-    const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
+    // K-major operand: K rows of lda elements, M valid columns; rows past K are beyond num_records and read as zeros
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(A), 0, (int)(uint32_t)(TA ? ((g.K - 1) * g.lda * 2 + g.M * 2) : ((g.M - 1) * g.lda * 2 + g.K * 2)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(B), 0, (int)(uint32_t)(TB ? ((g.K - 1) * g.ldb * 2 + g.N * 2) : ((g.N - 1) * g.ldb * 2 + g.K * 2)), 0x00020000);
+    const u32x4_t rs4_a = gemm_rsrc4(A, (uint32_t)(TA ? ((g.K - 1) * g.lda * 2 + g.M * 2) : ((g.M - 1) * g.lda * 2 + g.K * 2)));
+    const u32x4_t rs4_b = gemm_rsrc4(B, (uint32_t)(TB ? ((g.K - 1) * g.ldb * 2 + g.N * 2) : ((g.N - 1) * g.ldb * 2 + g.K * 2)));
+    const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    // scalar byte step of the DMA source: 64 k = 128 bytes along a row per K-tile (K-contiguous operand), or 16 rows (K-major: a
+    // K-tile is four such steps)
+    const uint32_t ksa = TA ? (uint32_t)(g.lda * 32) : 128u, ksb = TB ? (uint32_t)(g.ldb * 32) : 128u;
     const int swz = (lane & 15) >> 1;
     int ra[2], rb[2], ra_hi[2], rb_hi[2];
 #pragma unroll
@@ -2349,6 +2533,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         rb_hi[ks] = rb[ks] + TILE;
         asm volatile("" : "+v"(ra_hi[ks]), "+v"(rb_hi[ks]));
     }
+    // transpose-read lane constants (K-major operands): k-row (8 g + (r >> 2)) of the k-step | the wave's 256-byte half row | the
+    // swizzle f of that k-row in the block field | the lane's 8 bytes of its 32-byte block (+ operand region and buffer)
+    constexpr bool ra_T = TA, rb_T = TB;
+    const int tr_lane = (((lane >> 4) * 8 + ((lane & 15) >> 2)) * 512) | (((((lane & 15) >> 2) & 3) | (((lane >> 4) & 1) << 2)) * 32) | ((lane & 3) * 8);
+    int ra_tb[2], rb_tb[2];
+    ra_tb[0] = tr_lane | (wm * 256);
+    rb_tb[0] = (BM * 128) | tr_lane | (wn * 256);
+    ra_tb[1] = ra_tb[0] + TILE;
+    rb_tb[1] = rb_tb[0] + TILE;
+    asm volatile("" : "+v"(ra_tb[0]), "+v"(rb_tb[0]), "+v"(ra_tb[1]), "+v"(rb_tb[1]));
 #define TMARK(K_)                                                                                                         \
     do {                                                                                                                  \
         if ((g.dbg & 64) && (blockIdx.x == 0 || blockIdx.x == 131) && lane == 0 && tcount < 8)                            \
@@ -2356,19 +2550,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     } while (0)
     int tcount = 0;
 #define SB() __builtin_amdgcn_sched_barrier(0)
-#define LDF(dst, base_lo, base_hi, BUFV, KS, I) dst = *reinterpret_cast<const bf16x8_t*>(smem + (((BUFV) & 1) ? base_hi[KS] : base_lo[KS]) + (I) * 2048)
+#define LDF(dst, base_lo, base_hi, BUFV, KS, I)                                                                                     \
+    do {                                                                                                                          \
+        if constexpr (base_lo##_T) dst = ldf_tr<(I)>(smem, base_lo##_tb[(BUFV) & 1], (KS) * 16384);                                  \
+        else dst = *reinterpret_cast<const bf16x8_t*>(smem + (((BUFV) & 1) ? base_hi[KS] : base_lo[KS]) + (I) * 2048);              \
+    } while (0)
 
     const int ntiles = g.gm * g.gn;
     uint32_t oa[8], ob[8];
     // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
     auto dma = [&](int bufv, int kt, int p) {
         const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
-        if (p < 8)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p & 7],
-                                                     kt * 128, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 7],
-                                                     kt * 128, 0, 0);
+        // K-major operand: piece i = k-rows 8 i + (tid >> 5); pieces i and i + 2 differ by 16 rows = a UNIFORM byte offset, and the
+        // swizzle of a row depends on i only through its parity -- two per-lane offsets (even / odd pieces) instead of eight, the rest
+        // rides in the scalar offset (the register file of this kernel is full: 256 accumulators + 128 fragment registers)
+        if constexpr ((TA || TB) && !(OTTER_KMDBG & 2)) {   // asm issue for BOTH operands of a K-major instantiation (see gemm_dma16_asm)
+            const unsigned dst = smem_lds + (unsigned)wbase;
+            if (p < 8) {
+                if constexpr (TA) gemm_dma16_asm(rs4_a, dst, oa[p & 1], (uint32_t)(4 * kt + ((p & 7) >> 1)) * ksa);   // (OTTER_KMDBG: debug builds)
+                else gemm_dma16_asm(rs4_a, dst, oa[p & 7], (uint32_t)kt * ksa);
+            } else {
+                if constexpr (TB) gemm_dma16_asm(rs4_b, dst, ob[p & 1], (uint32_t)(4 * kt + ((p & 7) >> 1)) * ksb);
+                else gemm_dma16_asm(rs4_b, dst, ob[p & 7], (uint32_t)kt * ksb);
+            }
+        } else if (p < 8) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[TA ? (p & 1) : (p & 7)],
+                                                     (int)((TA ? (uint32_t)(4 * kt + ((p & 7) >> 1)) : (uint32_t)kt) * ksa), 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[TB ? (p & 1) : (p & 7)],
+                                                     (int)((TB ? (uint32_t)(4 * kt + ((p & 7) >> 1)) : (uint32_t)kt) * ksb), 0, 0);
+        }
     };
     for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
         int tile_m, tile_n;
@@ -2381,8 +2592,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             const int slot = phys ^ ((row >> 1) & 7);
             int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
             int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
-            oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
-            ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
+            // K-major operand: 16-byte chunk c of the [64 k][256 m] tile = k-row c >> 5, physical 16-byte slot c & 31; the 32-byte
+            // block index is un-swizzled by f(k-row) to find the source columns (columns past M / N only feed output rows that are
+            // never stored; rows past K are outside the descriptor and read as zeros)
+            const int krow = c >> 5, c16 = c & 31;
+            const int mlog = ((((c16 >> 1) ^ ((krow & 3) | (((krow >> 3) & 1) << 2))) << 1) | (c16 & 1)) * 8;
+            if constexpr (TA) { if (i < 2) oa[i] = ((uint32_t)krow * (uint32_t)g.lda + (uint32_t)m0 + (uint32_t)mlog) * 2u; }
+            else oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
+            if constexpr (TB) { if (i < 2) ob[i] = ((uint32_t)krow * (uint32_t)g.ldb + (uint32_t)n0 + (uint32_t)mlog) * 2u; }
+            else ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
         }
         // ---- prologue: K-tiles 0 and 1 in flight, 0 readable; the 256 accumulator registers are zeroed while they land ----
 #pragma unroll
@@ -2391,12 +2609,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         for (int p = 0; p < 16; ++p) dma(1, 1, p);
         __builtin_amdgcn_sched_barrier(0);
         f32x4_t acc[8][8];
+        constexpr bool XACC = (TA || TB) && !(OTTER_KMDBG & 1);   // accumulators in explicit AGPRs (asm MFMAs)
+        if constexpr (XACC) {
+            ACC_ZERO_ROW(0); ACC_ZERO_ROW(1); ACC_ZERO_ROW(2); ACC_ZERO_ROW(3); ACC_ZERO_ROW(4); ACC_ZERO_ROW(5); ACC_ZERO_ROW(6); ACC_ZERO_ROW(7);
+        } else {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+            for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 8; ++ni)
+                for (int ni = 0; ni < 8; ++ni)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -2404,11 +2627,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         bf16x8_t fm[2][8], fn[2][8];  // [k-step][16-row block]: fm = A rows (b-operand), fn = B rows (a-operand)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            LDF(fm[0][i], ra, ra_hi, 0, 0, i);
-            LDF(fn[0][i], rb, rb_hi, 0, 0, i);
+            if constexpr (TA) fm[0][i] = ldf_tr_rt(smem, ra_tb[0], 0, i);
+            else fm[0][i] = *reinterpret_cast<const bf16x8_t*>(smem + ra[0] + i * 2048);
+            if constexpr (TB) fn[0][i] = ldf_tr_rt(smem, rb_tb[0], 0, i);
+            else fn[0][i] = *reinterpret_cast<const bf16x8_t*>(smem + rb[0] + i * 2048);
         }
         TMARK(1);
-#define MMA(KS, MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0)
+// K-major instantiations: asm MFMAs on explicit AGPR blocks (see AC_mi_ni above).  With the builtin, hipcc's register allocator gives up
+// on these variants (two 64-bit transpose reads per fragment instead of one 128-bit read): accumulators end up in VGPRs, every MFMA
+// result is copied out of a[0:3] and ~1 400 v_accvgpr_* / 360 s_nop land in the K loop (2x slower, measured).  MFMAs on one block are 64
+// slots apart; the wait states before the tail's reads are spelled out after the loop.
+#define MMA(KS, MI, NI)                                                                                                             \
+    do {                                                                                                                          \
+        if constexpr (XACC)                                                                                                        \
+            asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"                                                  \
+                         : : "v"(fn[KS][NI]), "v"(fm[KS][MI]), "n"(((MI) * 8 + (NI)) * 4), "n"(((MI) * 8 + (NI)) * 4 + 3) : AC_##MI##_##NI); \
+        else acc[MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0);                  \
+    } while (0)
 // ---- GENERATED by tools/gen/gemm_t4_schedule.py (do not edit by hand) ----
 #define KTILE_T0(BUF, TV, DMA, NEXT)                                                                                                                                                            \
     do {                                                                                                                                                                                        \
@@ -2964,18 +3199,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #undef MMA
 
         // ---- epilogue: both buffers are dead (every fragment read retired before barrier #1 of the last K-tile, no DMA in flight) ----
+        // asm MFMAs (K-major instantiations): hipcc does not know their latency, so the wait states between the last MFMAs and the
+        // first accumulator reads of the tail are spelled out (a 16x16x32 result is readable 8 passes + 2 after issue)
+        // the tail then parks them straight out of the AGPR half (park_stripe(AgprAcc)).
+        if constexpr (XACC) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
         TMARK(2);
         float part = 0.f;
         const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (g.cdt == OTTER_F32 || g.wide);
+        const AgprAcc xacc;
         if (full) {
             float* blk4 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
-            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
-            else part = tail_wave_full<EPI, false>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+            if constexpr (XACC) {
+                if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, xacc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+                else part = tail_wave_full<EPI, false>(g, sgate, xacc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+            } else {
+                if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+                else part = tail_wave_full<EPI, false>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+            }
         } else {
             float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                park_stripe(blk, acc, st, lane);
+                if constexpr (XACC) park_stripe(blk, xacc, st, lane);
+                else park_stripe(blk, acc, st, lane);
                 __builtin_amdgcn_wave_barrier();
                 part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 128 + (st >> 1) * 32, n0 + wn * 128 + (st & 1) * 64, lane);
                 __builtin_amdgcn_wave_barrier();
@@ -3438,6 +3684,19 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         if (!once) { int rc = set_smem(gemm_bf16_t4_kernel<EPI, SCH_>, smem); if (rc) return rc; once = true; }            \
         hipLaunchKernelGGL((gemm_bf16_t4_kernel<EPI, SCH_>), dim3(pg), dim3(256), smem, st, g);                            \
     } while (0)
+#define LAUNCH_T4T(TA_, TB_)                                                                                               \
+    do {                                                                                                                   \
+        static bool once = false;                                                                                          \
+        if (!once) { int rc = set_smem(gemm_bf16_t4_kernel<EPI, 0, TA_, TB_>, smem); if (rc) return rc; once = true; }     \
+        hipLaunchKernelGGL((gemm_bf16_t4_kernel<EPI, 0, TA_, TB_>), dim3(pg), dim3(256), smem, st, g);                     \
+    } while (0)
+        if (g.ta || g.tb) {   // K-major operands: the backward products (dW = dy^T x: both; dx = dy W: B)
+            if (g.ta && g.tb) LAUNCH_T4T(true, true);
+            else if (g.tb) LAUNCH_T4T(false, true);
+            else LAUNCH_T4T(true, false);
+            return OTTER_OK;
+        }
+#undef LAUNCH_T4T
 #ifdef OTTER_EXPERIMENTAL
         if (cfg == CFG_T4) LAUNCH_T4(0);
         else if (cfg == CFG_T4B) LAUNCH_T4(1);
@@ -3541,8 +3800,36 @@ int64_t otter_gemm_num_partials(int64_t M, int64_t N, int ab_dtype) {
     return cdiv64(M, bm) * cdiv64(N, bn);
 }
 
+int otter_gemm_kmajor_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int a_kmajor, int b_kmajor, int ab_dtype) {
+    if (ab_dtype != OTTER_BF16 || g_variant != 0) return 0;
+    if (K % 128 != 0 || K < 128) return 0;                               // the register-resident K-tile pipeline (variant 26)
+    if (cdiv64(M, 256) * cdiv64(N, 256) < 192) return 0;                 // small grids run the ring kernel on K-contiguous operands
+    if (a_kmajor && (M % 8 != 0 || lda % 8 != 0)) return 0;              // 16-byte chunks along the rows
+    if (b_kmajor && (N % 8 != 0 || ldb % 8 != 0)) return 0;
+    const int64_t span_a = a_kmajor ? ((K - 1) * lda + M) * 2 : ((M - 1) * lda + K) * 2;
+    const int64_t span_b = b_kmajor ? ((K - 1) * ldb + N) * 2 : ((N - 1) * ldb + K) * 2;
+    return span_a < (int64_t(1) << 32) && span_b < (int64_t(1) << 32);
+}
+
+static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N,
+                     int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream);
+
 int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                   int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream) {
+    return gemm_impl(A, lda, 0, B, ldb, 0, C, ldc, M, N, K, ab_dtype, c_dtype, epi, stream);
+}
+
+int otter_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N,
+               int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream) {
+    if (a_kmajor || b_kmajor)
+        OTTER_REQUIRE(otter_gemm_kmajor_supported(M, N, K, lda, ldb, a_kmajor, b_kmajor, ab_dtype),
+                      "gemm: K-major operands need bf16, K %% 128 == 0, >= 192 tiles of 256x256, M / N / ld %% 8 == 0 and < 4 GB per operand "
+                      "(M=%ld N=%ld K=%ld): ask otter_gemm_kmajor_supported first and transpose otherwise", (long)M, (long)N, (long)K);
+    return gemm_impl(A, lda, a_kmajor ? 1 : 0, B, ldb, b_kmajor ? 1 : 0, C, ldc, M, N, K, ab_dtype, c_dtype, epi, stream);
+}
+
+static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N,
+                     int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream) {
     OTTER_REQUIRE(A && B && C && epi, "gemm: null pointer");
     OTTER_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     const int kal = ab_dtype == OTTER_BF16 ? 8 : 4;
@@ -3576,8 +3863,10 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
             OTTER_FAIL(OTTER_ERR_ARG, "gemm: unknown epilogue %d", g.kind);
     }
     const int64_t esz = ab_dtype == OTTER_BF16 ? 2 : 4;
-    const bool wide = ((M - 1) * lda + K) * esz >= (int64_t(1) << 32) || ((N - 1) * ldb + K) * esz >= (int64_t(1) << 32);
-    const int cfg = pick_cfg(M, N, K, ab_dtype, wide);
+    const bool kmaj = a_kmajor || b_kmajor;
+    const bool wide = !kmaj && (((M - 1) * lda + K) * esz >= (int64_t(1) << 32) || ((N - 1) * ldb + K) * esz >= (int64_t(1) << 32));
+    const int cfg = kmaj ? CFG_T4 : pick_cfg(M, N, K, ab_dtype, wide);
+    g.ta = a_kmajor; g.tb = b_kmajor;
     int bm, bn;
     cfg_tiles(cfg, bm, bn);
     g.dbg = g_debug;

@@ -182,15 +182,16 @@ def rmsnorm_bwd_ex(dy, x2d, w, rstd, dx_dtype, dres=None, need_dw=False, dx_bf16
 
 
 def gemm_nt(A, B, out_dtype=None, out=None, kind=EPI_STORE, gate=None, R=None, C2=None, aux=None, aux_gelu=False,
-            partial=None, accumulate=False, k=None):
+            partial=None, accumulate=False, k=None, a_kmajor=False, b_kmajor=False):
     """C[M,N] = epilogue(A[M,K] . B[N,K]^T).  A, B row-major 2-D (row stride free), same dtype.
-    `k` restricts the reduction to the first k columns (used with zero-padded transposed operands)."""
+    `k` restricts the reduction to the first k columns (used with zero-padded transposed operands).
+    a_kmajor / b_kmajor (see `gemm`): the operand is given as [K, M] / [K, N] instead."""
     K.require_cuda(A, B)
     A, B = _c2d(A), _c2d(B)
     if A.dtype != B.dtype:
         raise K.OtterHipError(f"gemm: operand dtypes differ ({A.dtype} vs {B.dtype})")
-    M, Ka = A.shape
-    N, Kb = B.shape
+    M, Ka = (A.shape[1], A.shape[0]) if a_kmajor else A.shape
+    N, Kb = (B.shape[1], B.shape[0]) if b_kmajor else B.shape
     Kd = k if k is not None else Ka
     if Kd > Ka or Kd > Kb or (k is None and Ka != Kb):
         raise K.OtterHipError(f"gemm: K mismatch A{tuple(A.shape)} B{tuple(B.shape)} k={k}")
@@ -216,9 +217,26 @@ def gemm_nt(A, B, out_dtype=None, out=None, kind=EPI_STORE, gate=None, R=None, C
     e.partial = K.ptr(partial)
     if _GEMM_LOG is not None:
         _GEMM_LOG[(M, N, Kd, kind, str(A.dtype).split(".")[-1], str(out.dtype).split(".")[-1])] += 1
+    if a_kmajor or b_kmajor:
+        K.check(K.lib().otter_gemm(A.data_ptr(), A.stride(0), 1 if a_kmajor else 0, B.data_ptr(), B.stride(0), 1 if b_kmajor else 0, out.data_ptr(),
+                                   out.stride(0), M, N, Kd, K.dt(A), K.dt(out), C.byref(e), K.stream()), "gemm")
+        return out
     K.check(K.lib().otter_gemm_nt(A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0), M, N, Kd,
                                   K.dt(A), K.dt(out), C.byref(e), K.stream()), "gemm_nt")
     return out
+
+
+def gemm_kmajor_supported(M, N, Kd, lda, ldb, a_kmajor, b_kmajor, dtype) -> bool:
+    """True when otter_gemm takes these operands in place (K-major = [K rows][M or N columns]); else transpose + gemm_nt."""
+    if dtype != torch.bfloat16:
+        return False
+    return bool(K.lib().otter_gemm_kmajor_supported(int(M), int(N), int(Kd), int(lda), int(ldb), 1 if a_kmajor else 0, 1 if b_kmajor else 0, BF16))
+
+
+def gemm(A, B, a_kmajor=False, b_kmajor=False, **kw):
+    """C = epilogue(op(A) . op(B)^T) with K-MAJOR operands read in place: a_kmajor -> A is [K, M] (the reduction index is the row
+    index), b_kmajor -> B is [K, N].  dW = dy^T x is gemm(dy, x, True, True); dx = dy W (W stored [out, in]) is gemm(dy, W, False, True)."""
+    return gemm_nt(A, B, a_kmajor=a_kmajor, b_kmajor=b_kmajor, **kw)
 
 
 def gemm_num_partials(M, N, dtype) -> int:

@@ -473,6 +473,74 @@ def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt):
         assert abs(dg - want) < 1e-5 * scale + 1e-3
 
 
+KMAJOR_CASES = [
+    # (M, N, K, a_kmajor, b_kmajor, extra leading-dimension padding): >= 192 tiles of 256 x 256, K % 128 == 0
+    (4096, 4096, 256, True, True, 0),       # wgrad form, square grid
+    (4096, 4096, 256, False, True, 0),      # dgrad form (W as stored)
+    (4096, 4096, 256, True, False, 0),
+    (3592, 3600, 384, True, True, 8),       # ragged M / N edges (multiples of 8, not of 256) + padded leading dimensions
+    (3592, 3600, 384, False, True, 24),
+    (4096, 16384, 512, True, True, 0),      # the FFN weight-gradient aspect ratio
+]
+
+
+@pytest.mark.parametrize("M,N,Kd,ta,tb,pad", KMAJOR_CASES)
+def test_gemm_kmajor_operands(ops, M, N, Kd, ta, tb, pad):
+    """otter_gemm with K-major operands (round 3: transpose reads in the kernel instead of transpose kernels in HBM) against the SAME
+    product issued on explicitly transposed copies through otter_gemm_nt -- identical fragments and accumulation order, so the fp32
+    results must agree bit for bit -- and against the fp64 product on sampled rows; asymmetric random operands (a swapped or
+    mis-swizzled block cannot pass); fp32 and bf16 outputs; the fused gate and accumulate forms of the weight-gradient call."""
+    from otter_amd._capi import EPI_GATE_BWD, EPI_STORE
+
+    r = rng(M + 3 * N + Kd + ta + 2 * tb)
+    A = bf16_round(r.standard_normal((M, Kd)).astype(np.float32) * 0.5)     # logical [M, K]
+    B = bf16_round(r.standard_normal((N, Kd)).astype(np.float32) * 0.5)     # logical [N, K]
+
+    def operand(X, kmajor):
+        t = to_dev(X, torch.bfloat16)
+        if not kmajor:
+            return t
+        rows, cols = X.shape[1], X.shape[0]                  # stored [K, rows_of_X]
+        buf = torch.full((rows, cols + pad), float("nan"), dtype=torch.bfloat16, device=DEV)   # NaN padding: never read into a valid output
+        buf[:, :cols] = t.t()
+        return buf[:, :cols]
+
+    dA, dB = operand(A, ta), operand(B, tb)
+    assert ops.gemm_kmajor_supported(M, N, Kd, dA.stride(0), dB.stride(0), ta, tb, torch.bfloat16)
+    C = ops.gemm(dA, dB, ta, tb, out_dtype=torch.float32)
+    base = ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16), out_dtype=torch.float32)
+    assert torch.equal(C, base)
+    rows = np.unique(np.concatenate([[0, 255, 256, M - 1], r.integers(0, M, 60)]))
+    ref = A[rows].astype(np.float64) @ B.astype(np.float64).T
+    assert relmax(host(C)[rows], ref) < 1e-4
+    Cb = ops.gemm(dA, dB, ta, tb)
+    assert Cb.dtype == torch.bfloat16 and torch.equal(Cb, ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16)))
+    gate = to_dev(np.array([0.4], np.float32))
+    acc = ops.gemm(dA, dB, ta, tb, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
+    ops.gemm(dA, dB, ta, tb, out=acc, kind=EPI_STORE, accumulate=True)
+    want = ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16), out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
+    ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16), out=want, kind=EPI_STORE, accumulate=True)
+    assert torch.equal(acc, want)
+    if not ta and tb and pad == 0:       # the dgrad-with-GELU-backward launch (dU = (dy W2) tanh(g) gelu'(u))
+        aux = to_dev(bf16_round(r.standard_normal((M, N)).astype(np.float32)), torch.bfloat16)
+        p1 = torch.zeros(ops.gemm_num_partials(M, N, torch.bfloat16), dtype=torch.float32, device=DEV)
+        p2 = torch.zeros_like(p1)
+        x1 = ops.gemm(dA, dB, ta, tb, kind=EPI_GATE_BWD, gate=gate, aux=aux, aux_gelu=True, partial=p1)
+        x2 = ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16), kind=EPI_GATE_BWD, gate=gate, aux=aux, aux_gelu=True, partial=p2)
+        assert torch.equal(x1, x2) and torch.equal(p1, p2)
+
+
+def test_gemm_kmajor_unsupported_shapes_are_refused(ops):
+    from otter_amd import _capi
+
+    A = torch.zeros((256, 512), dtype=torch.bfloat16, device=DEV)      # [K=256, M=512]: 2 x 2 tiles -> small grid
+    assert not ops.gemm_kmajor_supported(512, 512, 256, 512, 512, True, True, torch.bfloat16)
+    with pytest.raises(_capi.OtterHipError, match="K-major operands need"):
+        ops.gemm(A, A, True, True)
+    assert not ops.gemm_kmajor_supported(4096, 4096, 192, 4096, 4096, True, True, torch.bfloat16)     # K % 128
+    assert not ops.gemm_kmajor_supported(4096, 4092, 256, 4096, 4092, True, True, torch.bfloat16)     # N % 8
+
+
 def test_gemm_big_variants_agree(ops):
     """All three bf16 schedules produce the same numbers on the FFN shape class (256-multiple tiles, K=1024)."""
     r = rng(3)
