@@ -2380,38 +2380,38 @@ __device__ __forceinline__ u32x4_t gemm_rsrc4(const void* p, uint32_t bytes) {
     return r;
 }
 __device__ __forceinline__ void gemm_dma16_asm(u32x4_t r, unsigned lds, uint32_t voff, uint32_t soff) {
-    unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    // M0 is clobbered, not restored: nothing else in a K-major instantiation uses it (every LDS-DMA of the kernel is this statement), and
+    // with one wave per SIMD every instruction beside an MFMA is an issue slot -- the save / restore / settle form of csrc/flash.hip
+    // (6 instructions, > 16 cycles) stalled the matrix pipe at each of the 16 pieces of a K-tile (measured: 449 vs 379 us).
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    // (m0 cannot be named as a clobber -- it is a reserved register to hipcc, which never keeps a value in it across statements: every
+    //  compiler-generated use is preceded by its own s_mov)
 }
 
 // Address of a transpose read: k-row, half row, swizzled block and the lane's 8 bytes occupy DISJOINT bit fields of the LDS
 // offset (bits 9-13 | 8 | 5-7 | 3-4; the +4 rows of the second read, the k-step, the operand region and the buffer are higher or
 // free bits), so  row*512 + half*256 + ((i ^ f) * 32) + 8 (r & 3)  ==  lane_const ^ (i * 32): ONE v_xor_b32 with a literal per
-// fragment, everything else rides in the instruction's immediate offset.  The xor is an asm volatile on purpose: its 28 possible
-// values per lane are loop invariant, hipcc hoists them out of the K loop, and the kernel (256 accumulator + 128 fragment registers)
-// then spills 80-130 registers to scratch.
+// fragment, everything else rides in the instruction's immediate offset (lane_const is an ABSOLUTE LDS address: no symbol add).  The
+// 28 possible values per lane are loop invariant and hipcc would hoist them out of the K loop (28 more live registers in a kernel
+// whose file is full): the lane constants are therefore passed through an empty asm once per K-tile (LDF macro), which makes them
+// opaque per iteration at no instruction.
 template <int I>
-__device__ __forceinline__ bf16x8_t ldf_tr(const char* __restrict__ smem, int lane_const, int koff) {
+__device__ __forceinline__ bf16x8_t ldf_tr(unsigned lane_const /* absolute LDS byte address */, int koff) {
     typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
     typedef short s16x8_t_ __attribute__((ext_vector_type(8)));
-    int a = lane_const;
-    if constexpr (I != 0) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a) : "n"(I * 32), "v"(lane_const));
-    const char* p = smem + a + koff;
-    const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p));
-    const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p + 2048));
+    const unsigned a = lane_const ^ (unsigned)(I * 32);
+    const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(uintptr_t)(a + (unsigned)koff));
+    const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(uintptr_t)(a + (unsigned)koff + 2048u));
     const s16x8_t_ r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, r);
 }
 // run-time block index (the prologue's unrolled loop)
-__device__ __forceinline__ bf16x8_t ldf_tr_rt(const char* __restrict__ smem, int lane_const, int koff, int i) {
+__device__ __forceinline__ bf16x8_t ldf_tr_rt(unsigned lane_const, int koff, int i) {
     typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
     typedef short s16x8_t_ __attribute__((ext_vector_type(8)));
-    int a;
-    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a) : "s"(i * 32), "v"(lane_const));
-    const char* p = smem + a + koff;
-    const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p));
-    const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(p + 2048));
+    const unsigned a = lane_const ^ (unsigned)(i * 32);
+    const s16x4_t_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(uintptr_t)(a + (unsigned)koff));
+    const s16x4_t_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(uintptr_t)(a + (unsigned)koff + 2048u));
     const s16x8_t_ r = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, r);
 }
@@ -2537,9 +2537,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     // swizzle f of that k-row in the block field | the lane's 8 bytes of its 32-byte block (+ operand region and buffer)
     constexpr bool ra_T = TA, rb_T = TB;
     const int tr_lane = (((lane >> 4) * 8 + ((lane & 15) >> 2)) * 512) | (((((lane & 15) >> 2) & 3) | (((lane >> 4) & 1) << 2)) * 32) | ((lane & 3) * 8);
-    int ra_tb[2], rb_tb[2];
-    ra_tb[0] = tr_lane | (wm * 256);
-    rb_tb[0] = (BM * 128) | tr_lane | (wn * 256);
+    const unsigned smem_abs = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    if ((TA || TB) && (smem_abs & 255u)) __builtin_trap();   // the xor addressing needs the dynamic LDS region on a bank-row boundary (it starts at 0)
+    unsigned ra_tb[2], rb_tb[2];
+    ra_tb[0] = smem_abs + (unsigned)(tr_lane | (wm * 256));
+    rb_tb[0] = smem_abs + (unsigned)((BM * 128) | tr_lane | (wn * 256));
     ra_tb[1] = ra_tb[0] + TILE;
     rb_tb[1] = rb_tb[0] + TILE;
     asm volatile("" : "+v"(ra_tb[0]), "+v"(rb_tb[0]), "+v"(ra_tb[1]), "+v"(rb_tb[1]));
@@ -2552,8 +2554,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define LDF(dst, base_lo, base_hi, BUFV, KS, I)                                                                                     \
     do {                                                                                                                          \
-        if constexpr (base_lo##_T) dst = ldf_tr<(I)>(smem, base_lo##_tb[(BUFV) & 1], (KS) * 16384);                                  \
+        if constexpr (base_lo##_T) {                                                                                              \
+            if constexpr ((I) == 0) asm volatile("" : "+v"(base_lo##_tb[(BUFV) & 1]));   /* opaque per use of block 0: no hoisting */   \
+            dst = ldf_tr<(I)>(base_lo##_tb[(BUFV) & 1], (KS) * 16384);                                                              \
+        }                                                                                                                         \
         else dst = *reinterpret_cast<const bf16x8_t*>(smem + (((BUFV) & 1) ? base_hi[KS] : base_lo[KS]) + (I) * 2048);              \
+    } while (0)
+
+    // split form (KTILE_X0): LDFA = address + first 64-bit transpose read (or the whole 128-bit read of a K-contiguous operand),
+    // LDFB = the second transpose read one MFMA slot later (nothing for a K-contiguous operand)
+    typedef short s16x4_t_ __attribute__((ext_vector_type(4)));
+    typedef short s16x8_t_ __attribute__((ext_vector_type(8)));
+    unsigned tr_addr = 0;
+    s16x4_t_ tr_lo = {0, 0, 0, 0};
+#define LDFA(dst, base_lo, base_hi, BUFV, KS, I)                                                                                    \
+    do {                                                                                                                          \
+        if constexpr (base_lo##_T) {                                                                                              \
+            if constexpr ((I) == 0) asm volatile("" : "+v"(base_lo##_tb[(BUFV) & 1]));                                             \
+            tr_addr = (base_lo##_tb[(BUFV) & 1] ^ (unsigned)((I) * 32)) + (unsigned)((KS) * 16384);                                  \
+            tr_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(uintptr_t)tr_addr);      \
+        } else dst = *reinterpret_cast<const bf16x8_t*>(smem + (((BUFV) & 1) ? base_hi[KS] : base_lo[KS]) + (I) * 2048);            \
+    } while (0)
+#define LDFB(dst, base_lo, base_hi, BUFV, KS, I)                                                                                    \
+    do {                                                                                                                          \
+        if constexpr (base_lo##_T) {                                                                                              \
+            const s16x4_t_ hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t_*)(uintptr_t)(tr_addr + 2048u)); \
+            const s16x8_t_ r_ = __builtin_shufflevector(tr_lo, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                                        \
+            dst = __builtin_bit_cast(bf16x8_t, r_);                                                                                \
+        }                                                                                                                         \
     } while (0)
 
     const int ntiles = g.gm * g.gn;
@@ -2627,9 +2655,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         bf16x8_t fm[2][8], fn[2][8];  // [k-step][16-row block]: fm = A rows (b-operand), fn = B rows (a-operand)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if constexpr (TA) fm[0][i] = ldf_tr_rt(smem, ra_tb[0], 0, i);
+            if constexpr (TA) fm[0][i] = ldf_tr_rt(ra_tb[0], 0, i);
             else fm[0][i] = *reinterpret_cast<const bf16x8_t*>(smem + ra[0] + i * 2048);
-            if constexpr (TB) fn[0][i] = ldf_tr_rt(smem, rb_tb[0], 0, i);
+            if constexpr (TB) fn[0][i] = ldf_tr_rt(rb_tb[0], 0, i);
             else fn[0][i] = *reinterpret_cast<const bf16x8_t*>(smem + rb[0] + i * 2048);
         }
         TMARK(1);
@@ -2775,6 +2803,138 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         MMA(1, 5, 7); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
         MMA(1, 6, 7); SB();                                                                                                                                                                     \
         MMA(1, 7, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+    } while (0)
+// K-major instantiations: split fragment reads (tools/gen/gemm_t4_schedule.py x0)
+#define KTILE_X0(BUF, TV, DMA, NEXT)                                                                                                                                                            \
+    do {                                                                                                                                                                                        \
+        MMA(0, 0, 0); SB(); LDFA(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                         \
+        MMA(0, 1, 0); SB(); LDFB(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                         \
+        MMA(0, 0, 1); SB(); LDFA(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                         \
+        MMA(0, 1, 1); SB(); LDFB(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                         \
+        MMA(0, 2, 0); SB(); LDFA(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                         \
+        MMA(0, 2, 1); SB(); LDFB(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                         \
+        MMA(0, 0, 2); SB(); LDFA(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                         \
+        MMA(0, 1, 2); SB(); LDFB(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                         \
+        MMA(0, 2, 2); SB(); LDFA(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                         \
+        MMA(0, 3, 0); SB(); LDFB(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                         \
+        MMA(0, 3, 1); SB(); LDFA(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                         \
+        MMA(0, 3, 2); SB(); LDFB(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                         \
+        MMA(0, 0, 3); SB(); LDFA(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                         \
+        MMA(0, 1, 3); SB(); LDFB(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                         \
+        MMA(0, 2, 3); SB(); LDFA(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                         \
+        MMA(0, 3, 3); SB(); LDFB(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                         \
+        MMA(0, 4, 0); SB(); LDFA(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                         \
+        MMA(0, 4, 1); SB(); LDFB(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                         \
+        MMA(0, 4, 2); SB(); LDFA(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                         \
+        MMA(0, 4, 3); SB(); LDFB(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                         \
+        MMA(0, 0, 4); SB(); LDFA(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                         \
+        MMA(0, 1, 4); SB(); LDFB(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                         \
+        MMA(0, 2, 4); SB(); LDFA(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                         \
+        MMA(0, 3, 4); SB(); LDFB(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                         \
+        MMA(0, 4, 4); SB(); LDFA(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                         \
+        MMA(0, 5, 0); SB(); LDFB(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                         \
+        MMA(0, 5, 1); SB(); LDFA(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                         \
+        MMA(0, 5, 2); SB(); LDFB(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                         \
+        MMA(0, 5, 3); SB(); LDFA(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                         \
+        MMA(0, 5, 4); SB(); LDFB(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                         \
+        MMA(0, 0, 5); SB(); LDFA(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                         \
+        MMA(0, 1, 5); SB(); LDFB(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                         \
+        MMA(0, 2, 5); SB();                                                                                                                                                                     \
+        MMA(0, 3, 5); SB();                                                                                                                                                                     \
+        MMA(0, 4, 5); SB();                                                                                                                                                                     \
+        MMA(0, 5, 5); SB();                                                                                                                                                                     \
+        MMA(0, 6, 0); SB();                                                                                                                                                                     \
+        MMA(0, 6, 1); SB();                                                                                                                                                                     \
+        MMA(0, 6, 2); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
+        MMA(0, 6, 3); SB();                                                                                                                                                                     \
+        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
+        MMA(0, 6, 5); SB();                                                                                                                                                                     \
+        MMA(0, 0, 6); SB();                                                                                                                                                                     \
+        MMA(0, 1, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
+        MMA(0, 2, 6); SB();                                                                                                                                                                     \
+        MMA(0, 3, 6); SB();                                                                                                                                                                     \
+        MMA(0, 4, 6); SB();                                                                                                                                                                     \
+        MMA(0, 5, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
+        MMA(0, 6, 6); SB();                                                                                                                                                                     \
+        MMA(0, 7, 0); SB();                                                                                                                                                                     \
+        MMA(0, 7, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
+        MMA(0, 7, 2); SB();                                                                                                                                                                     \
+        MMA(0, 7, 3); SB();                                                                                                                                                                     \
+        MMA(0, 7, 4); SB();                                                                                                                                                                     \
+        MMA(0, 7, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
+        MMA(0, 7, 6); SB();                                                                                                                                                                     \
+        MMA(0, 0, 7); SB();                                                                                                                                                                     \
+        MMA(0, 1, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
+        MMA(0, 2, 7); SB();                                                                                                                                                                     \
+        MMA(0, 3, 7); SB();                                                                                                                                                                     \
+        MMA(0, 4, 7); SB();                                                                                                                                                                     \
+        MMA(0, 5, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
+        MMA(0, 6, 7); SB();                                                                                                                                                                     \
+        MMA(0, 7, 7); SB();                                                                                                                                                                     \
+        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
+        MMA(1, 1, 0); SB();                                                                                                                                                                     \
+        MMA(1, 0, 1); SB();                                                                                                                                                                     \
+        MMA(1, 1, 1); SB();                                                                                                                                                                     \
+        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
+        MMA(1, 2, 1); SB();                                                                                                                                                                     \
+        MMA(1, 0, 2); SB();                                                                                                                                                                     \
+        MMA(1, 1, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
+        MMA(1, 2, 2); SB();                                                                                                                                                                     \
+        MMA(1, 3, 0); SB();                                                                                                                                                                     \
+        MMA(1, 3, 1); SB();                                                                                                                                                                     \
+        MMA(1, 3, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
+        MMA(1, 0, 3); SB();                                                                                                                                                                     \
+        MMA(1, 1, 3); SB();                                                                                                                                                                     \
+        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
+        MMA(1, 3, 3); SB();                                                                                                                                                                     \
+        MMA(1, 4, 0); SB();                                                                                                                                                                     \
+        MMA(1, 4, 1); SB();                                                                                                                                                                     \
+        MMA(1, 4, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
+        MMA(1, 4, 3); SB();                                                                                                                                                                     \
+        MMA(1, 0, 4); SB();                                                                                                                                                                     \
+        MMA(1, 1, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
+        MMA(1, 2, 4); SB();                                                                                                                                                                     \
+        MMA(1, 3, 4); SB();                                                                                                                                                                     \
+        MMA(1, 4, 4); SB();                                                                                                                                                                     \
+        MMA(1, 5, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
+        MMA(1, 5, 1); SB();                                                                                                                                                                     \
+        MMA(1, 5, 2); SB();                                                                                                                                                                     \
+        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
+        MMA(1, 5, 4); SB();                                                                                                                                                                     \
+        MMA(1, 0, 5); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
+        MMA(1, 1, 5); SB();                                                                                                                                                                     \
+        MMA(1, 2, 5); SB(); if (NEXT) { LDFA(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
+        MMA(1, 3, 5); SB(); if (NEXT) { LDFB(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
+        MMA(1, 4, 5); SB(); if (NEXT) { LDFA(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
+        MMA(1, 5, 5); SB(); if (NEXT) { LDFB(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
+        MMA(1, 6, 0); SB(); if (NEXT) { LDFA(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
+        MMA(1, 6, 1); SB(); if (NEXT) { LDFB(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
+        MMA(1, 6, 2); SB(); if (NEXT) { LDFA(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
+        MMA(1, 6, 3); SB(); if (NEXT) { LDFB(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
+        MMA(1, 6, 4); SB(); if (NEXT) { LDFA(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
+        MMA(1, 6, 5); SB(); if (NEXT) { LDFB(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
+        MMA(1, 0, 6); SB(); if (NEXT) { LDFA(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
+        MMA(1, 1, 6); SB(); if (NEXT) { LDFB(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
+        MMA(1, 2, 6); SB(); if (NEXT) { LDFA(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
+        MMA(1, 3, 6); SB(); if (NEXT) { LDFB(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
+        MMA(1, 4, 6); SB(); if (NEXT) { LDFA(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
+        MMA(1, 5, 6); SB(); if (NEXT) { LDFB(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
+        MMA(1, 6, 6); SB(); if (NEXT) { LDFA(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
+        MMA(1, 7, 0); SB(); if (NEXT) { LDFB(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
+        MMA(1, 7, 1); SB(); if (NEXT) { LDFA(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
+        MMA(1, 7, 2); SB(); if (NEXT) { LDFB(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
+        MMA(1, 7, 3); SB(); if (NEXT) { LDFA(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
+        MMA(1, 7, 4); SB(); if (NEXT) { LDFB(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
+        MMA(1, 7, 5); SB(); if (NEXT) { LDFA(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
+        MMA(1, 7, 6); SB(); if (NEXT) { LDFB(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
+        MMA(1, 0, 7); SB(); if (NEXT) { LDFA(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
+        MMA(1, 1, 7); SB(); if (NEXT) { LDFB(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
+        MMA(1, 2, 7); SB(); if (NEXT) { LDFA(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
+        MMA(1, 3, 7); SB(); if (NEXT) { LDFB(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
+        MMA(1, 4, 7); SB(); if (NEXT) { LDFA(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
+        MMA(1, 5, 7); SB(); if (NEXT) { LDFB(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
+        MMA(1, 6, 7); SB(); if (NEXT) { LDFA(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
+        MMA(1, 7, 7); SB(); if (NEXT) { LDFB(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
     } while (0)
 #ifdef OTTER_EXPERIMENTAL
 #define KTILE_T1(BUF, TV, DMA, NEXT)                                                                                                                                                            \
@@ -3192,9 +3352,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #undef KTILE_T3
 #else
         static_assert(SCH == 0, "the alternative placements of variant 26 (27-29) are in the OTTER_EXPERIMENTAL build only");
-        KLOOP(KTILE_T0);
+        if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP(KTILE_X0);
+        else KLOOP(KTILE_T0);
 #endif
 #undef KLOOP
+#undef KTILE_X0
 #undef KTILE_T0
 #undef MMA
 
@@ -3234,6 +3396,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         ++tcount;
     }
 #undef LDF
+#undef LDFA
+#undef LDFB
 #undef SB
 #undef TMARK
 }

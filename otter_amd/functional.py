@@ -106,6 +106,37 @@ def _wgrad(dyT: torch.Tensor, xT: torch.Tensor, gate=None, param=None):
     return ops.gemm_nt(dyT, xT, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
 
 
+def _wgrad_rows(dy_rows: torch.Tensor, x_rows: torch.Tensor, gate=None, param=None):
+    """dW[out,in] = (s *) dy^T . x from the operands AS THEY LIE in HBM -- dy [rows, out], x [rows, in], compute dtype -- through the
+    K-major GEMM (csrc/gemm.hip, transpose reads inside the kernel) when the shape qualifies; otherwise the operands are transposed
+    first (otter_transpose) and the K-contiguous kernels run.  Same sink protocol as _wgrad."""
+    rows, n_out = dy_rows.shape
+    n_in = x_rows.shape[1]
+    if (os.environ.get("OTTER_NO_KMAJOR") != "1"
+            and ops.gemm_kmajor_supported(n_out, n_in, rows, dy_rows.stride(0), x_rows.stride(0), True, True, dy_rows.dtype)):
+        out = grad_sink.take(param) if (grad_sink is not None and param is not None) else None
+        if out is not None:
+            ops.gemm(dy_rows, x_rows, True, True, out=out, kind=EPI_STORE, gate=gate)
+            grad_sink.ready(param)
+            return None
+        return ops.gemm(dy_rows, x_rows, True, True, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
+    cd = dy_rows.dtype
+    return _wgrad(ops.transpose(dy_rows, cd), ops.transpose(x_rows, cd), gate=gate, param=param)
+
+
+def _dgrad(dy_rows: torch.Tensor, W: torch.Tensor, cd, **epi):
+    """dx = epilogue(dy . W) for y = x W^T with W stored [out, in]: W is the K-major B operand of the product, read in place (no
+    transposed shadow of the weight: for the gated blocks' FFN matrices that is 2 x 128 MB per block rebuilt every optimizer step);
+    small / irregular shapes go through the transposed shadow and the K-contiguous kernels."""
+    rows, n_out = dy_rows.shape
+    n_in = W.shape[1]
+    Wc = shadows.w(W, cd)
+    if (os.environ.get("OTTER_NO_KMAJOR") != "1"
+            and ops.gemm_kmajor_supported(rows, n_in, n_out, dy_rows.stride(0), Wc.stride(0), False, True, dy_rows.dtype)):
+        return ops.gemm(dy_rows, Wc, False, True, **epi)
+    return ops.gemm_nt(dy_rows, shadows.wt(W, cd), **epi)
+
+
 def _flat_gate(g):
     if g.dtype != torch.float32:
         raise RuntimeError("gate parameters must be fp32 (1-element) tensors")
@@ -391,10 +422,10 @@ class LinearFn(torch.autograd.Function):
         x2, W = ctx.saved_tensors
         cd = x2.dtype
         dy = dy.contiguous()
-        dx = ops.gemm_nt(dy, shadows.wt(W, cd)) if ctx.needs_input_grad[0] else None
+        dx = _dgrad(dy, W, cd) if ctx.needs_input_grad[0] else None
         dW = None
         if ctx.needs_input_grad[1]:
-            dW = _wgrad(ops.transpose(dy, cd), ops.transpose(x2, cd), param=W)
+            dW = _wgrad_rows(dy, x2, param=W)
             dW = dW.to(W.dtype) if dW is not None else None
         return dx, dW
 
@@ -563,13 +594,14 @@ class GatedCrossAttentionFn(torch.autograd.Function):
         ga, gf = _flat_gate(attn_gate), _flat_gate(ff_gate)
         dy2 = dy.reshape(N, D).contiguous()
         # ---- feed-forward branch:  y = (h W2^T) tanh(gf) + x1 ----
-        dyT, dy_cd = ops.transpose(dy2, cd, want_same=True)
+        # every product reads its operands as they lie (K-major GEMM): no transposes of dy / h / dU / f, no W^T shadows of W1 / W2
+        dy_cd = dy2 if dy2.dtype == cd else ops.cast(dy2, cd)
         part = torch.empty(ops.gemm_num_partials(N, W1.shape[0], cd), dtype=torch.float32, device=dev)
-        dU = ops.gemm_nt(dy_cd, shadows.wt(W2, cd), kind=EPI_GATE_BWD, gate=gf, aux=u, aux_gelu=True, partial=part)
+        dU = _dgrad(dy_cd, W2, cd, kind=EPI_GATE_BWD, gate=gf, aux=u, aux_gelu=True, partial=part)
         d_ff_gate = ops.reduce_partials(part, gate=gf)
-        dW2 = _wgrad(dyT, ops.transpose(h, cd), gate=gf, param=W2)
-        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd), param=W1)
-        df = ops.gemm_nt(dU, shadows.wt(W1, cd))
+        dW2 = _wgrad_rows(dy_cd, h, gate=gf, param=W2)
+        dW1 = _wgrad_rows(dU, f, param=W1)
+        df = _dgrad(dU, W1, cd)
         dx1, dg2, db2 = ops.layernorm_bwd(df, x1, ffn_w.detach(), mean2, rstd2, rd, dres=dy2)
         # ---- attention branch:  x1 = (o Wo^T) tanh(ga) + x ----
         dx1T, dx1_cd = ops.transpose(dx1, cd, want_same=True)
@@ -650,11 +682,11 @@ class PerceiverBlockFn(torch.autograd.Function):
         nk = n1 + n2
         dy2 = dy.reshape(G * n2, D).contiguous()
         # feed-forward: y = gelu(f W1^T) W2^T + out1
-        dyT, dy_cd = ops.transpose(dy2, cd, want_same=True)
-        dU = ops.gemm_nt(dy_cd, shadows.wt(W2, cd), kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
-        dW2 = _wgrad(dyT, ops.transpose(h, cd), param=W2)
-        dW1 = _wgrad(ops.transpose(dU, cd), ops.transpose(f, cd), param=W1)
-        df = ops.gemm_nt(dU, shadows.wt(W1, cd))
+        dy_cd = dy2 if dy2.dtype == cd else ops.cast(dy2, cd)
+        dU = _dgrad(dy_cd, W2, cd, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+        dW2 = _wgrad_rows(dy_cd, h, param=W2)
+        dW1 = _wgrad_rows(dU, f, param=W1)
+        df = _dgrad(dU, W1, cd)
         dout1, dgf, dbf = ops.layernorm_bwd(df, out1, ff_w.detach(), mean_f, rstd_f, rd, dres=dy2)
         # attention: out1 = o Wo^T + latents
         d1T, d1_cd = ops.transpose(dout1, cd, want_same=True)

@@ -68,6 +68,56 @@ T1 = schedule("KTILE_T1", {r: [r] for r in range(16)}, 30, {32 + 4 * p: [p] for 
 T2 = schedule("KTILE_T2", {2 * r: [r] for r in range(16)}, 46, {48 + 4 * p: [p] for p in range(16)}, 106, {108 + r: [r] for r in range(16)})
 # T3: one barrier per K-tile (as KTILE_S3 of variant 22), X' reads on odd slots right after it
 T3 = schedule("KTILE_T3", {2 * r: [r] for r in range(16)}, 38, {40 + 4 * p: [p] for p in range(16)}, None, {41 + 2 * r: [r] for r in range(16)}, merged=True)
+
+
+def rd2(half, ks, r, buf):
+    t, i = FR[r]
+    return "LDF%s(f%s[%d][%d], %s, %s, %s, %d, %d);" % (half, t, ks, i, "rb" if t == "n" else "ra", "rb_hi" if t == "n" else "ra_hi", buf, ks, i)
+
+
+def schedule_split(name, b1, dma, b2):
+    """K-major instantiations (round 3): a transpose-read fragment is TWO LDS instructions (+ one v_xor); in one filler slot they take
+    longer to issue than the 16 cycles of the MFMA beside them (measured: +6.5 % on the launch).  Here every fragment read is split over
+    two adjacent slots (LDFA = address + first half, LDFB = second half; for a K-contiguous operand LDFA is the whole 128-bit read and
+    LDFB nothing): k-step-1 reads fill slots 0..31, the 16 DMA pieces move to slots 40..92 (all issued before barrier #2), the next
+    K-tile's k-step-0 reads fill slots 96..127."""
+    lines, issued = [], 0
+    for j in range(128):
+        ks, q = j >> 6, j & 63
+        mi, ni = ORD[q]
+        parts = ["MMA(%d, %d, %d); SB();" % (ks, mi, ni)]
+        if j < 32:
+            parts.append(rd2("AB"[j & 1], 1, j >> 1, "BUF") + " SB();")
+        if j == b1:
+            parts.append('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
+        for p in dma.get(j, []):
+            parts.append("if (DMA) dma(BUF, (TV) + 2, %d); SB();" % p)
+            issued += 1
+        if j == b2:
+            parts.append('if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(%d)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); '
+                         "__builtin_amdgcn_s_barrier(); } SB();" % issued)
+        if j >= 96:
+            parts.append("if (NEXT) { " + rd2("AB"[j & 1], 0, (j - 96) >> 1, "(BUF) ^ 1") + " } SB();")
+        lines.append("        " + " ".join(parts))
+    assert issued == 16
+    w = max(len(x) for x in lines) + 2
+    head = "#define %s(BUF, TV, DMA, NEXT)" % name
+    out = [head + " " * (w - len(head)) + "\\", "    do {" + " " * (w - 8) + "\\"]
+    out += [x + " " * (w - len(x)) + "\\" for x in lines]
+    out.append("    } while (0)")
+    return "\n".join(out)
+
+
+DMA_X = {}
+slot = 40
+for p_ in range(16):
+    DMA_X[slot] = [p_]
+    slot += 3 if p_ % 2 == 0 else 4
+X0 = schedule_split("KTILE_X0", 38, DMA_X, 94)
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "x0":
+    print(X0)
+    sys.exit(0)
 print(T0)
 print(T1)
 print(T2)
