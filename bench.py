@@ -252,7 +252,20 @@ def cpu_baseline(T=512):
               "fwd+dgrad (%.2fs), 6-layer perceiver fwd+bwd (%.2fs), 1 CLIP layer fwd (%.2fs), unembed+CE fwd+bwd (%.2fs); step "
               "time = 8*gated + 32*mpt + perceiver + 24*clip + unembed (optimizer/all-reduce not included)"
               % (t["gated_block"], t["mpt_block"], t["perceiver"], t["clip_layer"], t["unembed_loss"]))
-    return {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
+    out = {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
+    # calibration of the numpy port against the REFERENCE's own modules (torch CPU fp32), measured once in the build container where
+    # /root/reference exists (oracle/calibrate_cpu_baseline.py -> profiles/r03_cpu_baseline_calibration.json; it cannot travel to this box)
+    cal = os.path.join(ROOT, "profiles", "r03_cpu_baseline_calibration.json")
+    if os.path.exists(cal):
+        with open(cal) as f:
+            c = json.load(f)
+        r = c["step_mix"]["port_vs_reference"]
+        out["port_vs_reference"] = round(r, 3)
+        out["reference_equivalent_value"] = round(out["value"] / r, 5)
+        out["calibration"] = ("the reference's own modules (gated block, 6-layer perceiver, MPT block; fwd+bwd, fp32, %d threads, build container) run the "
+                              "same sample in %.2fx the time of the numpy port: reference-equivalent rate = value / port_vs_reference"
+                              % (c["host_threads"], r))
+    return out
 
 
 def gated_block_roofline(model, batch, B, T, device, iters=10):
@@ -387,7 +400,7 @@ def main():
         loss = one_step()
     sync()
     elapsed = time.perf_counter() - t0
-    n_launch, gemm_ms = ops.prof_collect()
+    n_launch, gemm_ms, n_km, km_ms = ops.prof_collect_split()
     ops.prof_disarm()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if use_dist:
@@ -413,6 +426,11 @@ def main():
             roof = {"bound": "mfma", "kernel": "%s M=%d N=%d K=%d" % (names.get(v, "gemm variant %d" % v), M, N, Kd), "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
+            # the same kernel runs in two operand layouts: K-contiguous rows (forward products) and K-major (round 3: the backward
+            # products read their operands in place through transpose reads); both are in `achieved`, split here
+            if n_km and n_launch > n_km:
+                roof["by_layout"] = {"k_contiguous": {"launches": n_launch - n_km, "avg_us": round((gemm_ms - km_ms) / (n_launch - n_km) * 1e3, 1)},
+                                     "k_major": {"launches": n_km, "avg_us": round(km_ms / n_km * 1e3, 1)}}
             if world == 1 and os.environ.get("OTTER_FORCE_DIST") != "1":   # (no DP reducer hooks on the parameters: stand-alone backward is safe)
                 roof["gated_block"] = gated_block_roofline(model, batch, B, T, device)
         out = {

@@ -163,6 +163,12 @@ int otter_gemm_variant_available(int variant);
  * torch DDP relies on the GPU scheduler).  Process-wide, like the other otter_gemm_set_* switches: set it from the thread that
  * launches the GEMMs, between steps. */
 int otter_gemm_set_cu_budget(int cus);
+/* on = 0: the large-grid kernel (variant 26) is launched with ONE workgroup per output tile instead of one persistent workgroup per CU.
+ * A persistent grid assumes it owns every CU: when a concurrent kernel (RCCL's all-reduce in the data-parallel step) holds a few CUs, the
+ * workgroups that could not start run their whole tile list AFTER the others finish and the launch takes twice as long; with one
+ * workgroup per tile the loss is proportional to the CUs taken (measured).  Costs ~8 us of fixed time per launch
+ * when nothing else runs.  Default 1.  Process-wide, set between steps. */
+int otter_gemm_set_persistent(int on);
 /* diagnostics for roofline ablations (results are WRONG when non-zero): bit0 = no global loads inside the K loop,
  * bit1 = no MFMAs.  Never set by the product path. */
 int otter_gemm_set_debug(int flags);
@@ -380,6 +386,8 @@ int otter_prof_arm_gemm(int64_t M, int64_t N, int64_t K, int max_events);
 int otter_gemm_read_timeline(unsigned long long* out, int n);
 int otter_prof_disarm(void);
 int otter_prof_collect(int* count, double* total_ms);
+/* same, with the launches that had a K-major operand (otter_gemm) counted separately as well (they are included in count / total_ms) */
+int otter_prof_collect_split(int* count, double* total_ms, int* count_kmajor, double* kmajor_ms);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@ SIGNATURES = {
     "otter_gemm_set_variant": (_int, [_int]),
     "otter_gemm_variant_available": (_int, [_int]),
     "otter_gemm_set_cu_budget": (_int, [_int]),
+    "otter_gemm_set_persistent": (_int, [_int]),
     "otter_gemm_set_debug": (_int, [_int]),
     "otter_gemm_read_timeline": (_int, [_vp, _int]),
     "otter_reduce_partials": (_int, [_vp, _i64, _vp, _vp, _int, _vp]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "otter_prof_arm_gemm": (_int, [_i64, _i64, _i64, _int]),
     "otter_prof_disarm": (_int, []),
     "otter_prof_collect": (_int, [C.POINTER(_int), C.POINTER(C.c_double)]),
+    "otter_prof_collect_split": (_int, [C.POINTER(_int), C.POINTER(C.c_double), C.POINTER(_int), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -3713,6 +3713,7 @@ void cfg_tiles(int cfg, int& bm, int& bn) {
 // kernels so the all-reduce of bucket i runs beside the dgrad GEMMs of the layers below instead of waiting for the gaps
 // between launches (every persistent GEMM otherwise pins all CUs with one 512-register wave per SIMD).
 int g_cu_budget = 0;   // 0 = all
+int g_persistent = 1;  // 0: the large-grid kernel (variant 26) runs one workgroup per tile (otter_gemm_set_persistent)
 unsigned device_cus() {
     static unsigned n = 0;
     if (n == 0) {
@@ -3735,6 +3736,7 @@ struct Prof {
     int max_events = 0, n = 0;
     hipEvent_t* start = nullptr;
     hipEvent_t* stop = nullptr;
+    unsigned char* kmajor = nullptr;   // per event: the launch had a K-major operand
 } g_prof;
 
 template <typename KernelT>
@@ -3841,7 +3843,7 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     if (cfg == CFG_T4 || cfg == CFG_T4B || cfg == CFG_T4C || cfg == CFG_T4M) {
         const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;
         unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
-        if (g_order & 0x10) pg = grid.x;   // diagnostics (otter_gemm_set_debug bit 13): one workgroup per tile instead of the persistent grid
+        if ((g_order & 0x10) || !g_persistent) pg = grid.x;   // one workgroup per tile (otter_gemm_set_persistent(0), or debug bit 13)
 #define LAUNCH_T4(SCH_)                                                                                                    \
     do {                                                                                                                   \
         static bool once = false;                                                                                          \
@@ -3923,6 +3925,11 @@ int otter_gemm_set_cu_budget(int cus) {
     if (cus < 0) OTTER_FAIL(OTTER_ERR_ARG, "gemm cu budget %d", cus);
     g_cu_budget = (cus > 0 && cus < 8) ? 8 : cus;   // at least one workgroup per XCD
     return (int)persistent_cus();
+}
+
+int otter_gemm_set_persistent(int on) {
+    g_persistent = on ? 1 : 0;
+    return OTTER_OK;
 }
 
 int otter_gemm_variant_available(int variant) {
@@ -4047,7 +4054,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
     if (prof) hipEventRecord(g_prof.start[g_prof.n], st);
     int rc = launch_cfg(cfg, g.kind, grid, st, g);
     if (rc) return rc;
-    if (prof) hipEventRecord(g_prof.stop[g_prof.n++], st);
+    if (prof) { g_prof.kmajor[g_prof.n] = (unsigned char)(kmaj ? 1 : 0); hipEventRecord(g_prof.stop[g_prof.n++], st); }
     OTTER_CHECK_LAUNCH("gemm");
     return OTTER_OK;
 }
@@ -4064,6 +4071,7 @@ int otter_prof_arm_gemm(int64_t M, int64_t N, int64_t K, int max_events) {
     OTTER_REQUIRE(max_events > 0 && max_events <= 65536, "prof: max_events");
     g_prof.start = new hipEvent_t[max_events];
     g_prof.stop = new hipEvent_t[max_events];
+    g_prof.kmajor = new unsigned char[max_events]();
     for (int i = 0; i < max_events; ++i) {
         hipEventCreate(&g_prof.start[i]);
         hipEventCreate(&g_prof.stop[i]);
@@ -4083,24 +4091,31 @@ int otter_prof_disarm(void) {
         }
         delete[] g_prof.start;
         delete[] g_prof.stop;
+        delete[] g_prof.kmajor;
     }
     g_prof = Prof();
     return OTTER_OK;
 }
 
-int otter_prof_collect(int* count, double* total_ms) {
+int otter_prof_collect_split(int* count, double* total_ms, int* count_kmajor, double* kmajor_ms) {
     OTTER_REQUIRE(count && total_ms, "prof_collect: null");
-    double tot = 0.0;
+    double tot = 0.0, km = 0.0;
+    int nk = 0;
     for (int i = 0; i < g_prof.n; ++i) {
         hipEventSynchronize(g_prof.stop[i]);
         float ms = 0.f;
         hipEventElapsedTime(&ms, g_prof.start[i], g_prof.stop[i]);
         tot += ms;
+        if (g_prof.kmajor[i]) { km += ms; ++nk; }
     }
     *count = g_prof.n;
     *total_ms = tot;
+    if (count_kmajor) *count_kmajor = nk;
+    if (kmajor_ms) *kmajor_ms = km;
     g_prof.n = 0;
     return OTTER_OK;
 }
+
+int otter_prof_collect(int* count, double* total_ms) { return otter_prof_collect_split(count, total_ms, nullptr, nullptr); }
 
 }  // extern "C"

@@ -583,6 +583,11 @@ def gemm_variant_available(v: int) -> bool:
     return bool(K.lib().otter_gemm_variant_available(int(v)))
 
 
+def set_gemm_persistent(on: bool) -> None:
+    """False: variant 26 runs one workgroup per tile (robust when RCCL kernels hold CUs during the backward GEMMs)."""
+    K.check(K.lib().otter_gemm_set_persistent(1 if on else 0), "gemm_set_persistent")
+
+
 def set_gemm_cu_budget(cus: int) -> int:
     """Cap the persistent GEMM grids at `cus` workgroups (0 = all CUs); returns the grid size in effect."""
     n = K.lib().otter_gemm_set_cu_budget(int(cus))
@@ -600,6 +605,14 @@ def prof_collect():
     ms = C.c_double(0.0)
     K.check(K.lib().otter_prof_collect(C.byref(n), C.byref(ms)), "prof_collect")
     return n.value, ms.value
+
+
+def prof_collect_split():
+    """(launches, total ms, launches with a K-major operand, their ms)."""
+    n, nk = C.c_int(0), C.c_int(0)
+    ms, mk = C.c_double(0.0), C.c_double(0.0)
+    K.check(K.lib().otter_prof_collect_split(C.byref(n), C.byref(ms), C.byref(nk), C.byref(mk)), "prof_collect_split")
+    return n.value, ms.value, nk.value, mk.value
 
 
 def prof_disarm():

@@ -219,6 +219,22 @@ class TrainStep:
         # single rank: gradients stay ordinary .grad tensors (no bucket indirection, nothing to reduce)
         self.reducer = (GradReducer(self.params, bucket_bytes, process_group, force=force_reducer, row_only=row_only)
                         if (self.world > 1 or force_reducer) else None)
+        # With a reducer live RCCL's kernels hold CUs during the backward GEMMs.  A persistent grid (one workgroup per CU walking 4 tiles)
+        # assumes it owns the chip: the workgroups that cannot start run their tile lists after the others have finished and the launch
+        # takes up to twice as long; capping the grid below the CU count is no better (1024 tiles / 248 CUs = a fifth round: +19 %,
+        # measured).  So the large GEMMs run one workgroup per tile while a reducer is attached (loss proportional to the CUs taken).
+        # OTTER_DP_PERSISTENT=1 keeps the persistent grids, OTTER_DP_CU_RESERVE=n caps them n below the CU count (A/B switches).
+        self.cu_reserve, self.nonpersistent = 0, False
+        if self.reducer is not None and dev.type == "cuda":
+            from . import ops
+
+            self.cu_reserve = int(os.environ.get("OTTER_DP_CU_RESERVE", "0"))
+            total = ops.set_gemm_cu_budget(0)
+            if self.cu_reserve > 0:
+                ops.set_gemm_cu_budget(max(total - self.cu_reserve, 8))
+            if os.environ.get("OTTER_DP_PERSISTENT") != "1":
+                ops.set_gemm_persistent(False)
+                self.nonpersistent = True
 
     def close(self):
         """Detach the DP reducer's autograd hooks and gradient sink (idempotent).  Call before building another TrainStep /
@@ -226,6 +242,14 @@ class TrainStep:
         red, self.reducer = getattr(self, "reducer", None), None
         if red is not None:
             red.close()
+            from . import ops
+
+            if getattr(self, "cu_reserve", 0) > 0:
+                ops.set_gemm_cu_budget(0)
+                self.cu_reserve = 0
+            if getattr(self, "nonpersistent", False):
+                ops.set_gemm_persistent(True)
+                self.nonpersistent = False
 
     def __del__(self):
         try:

@@ -25,6 +25,9 @@ for i in range(iters + 2):
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
+    for p in blk.parameters():
+        p.grad = None            # as after zero_grad(set_to_none=True): weight gradients are written, not accumulated
+    x.grad = None
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = blk(x, media, media_locations=ml, attend_previous=True)
     y.backward(dy)
