@@ -305,6 +305,68 @@ def gelu(u):
     return torch.nn.functional.gelu(u)
 
 
+class FrozenMLPFn(torch.autograd.Function):
+    """The frozen decoder MLP (mpt/blocks.py:37-49: down_proj(gelu(up_proj(x))), no biases, frozen weights) on csrc/gemm.hip with the
+    fusions a library GEMM cannot give: GELU in the up-projection's tail (the pre-activation u is stored beside
+    it for the backward; no separate GELU pass, no 128 MB round trip), GELU' in the tail of down_proj's input-gradient GEMM, and both
+    input-gradient products read the weights AS STORED through the K-major kernel (no transposed copies: 8.6 GB for MPT-7B).  Frozen
+    weights: there is no weight gradient, so h is not kept.  x2 [rows, D], weights in the compute dtype (bf16)."""
+
+    @staticmethod
+    def forward(ctx, x2, Wu, Wd):
+        need = ctx.needs_input_grad[0]
+        u = torch.empty((x2.shape[0], Wu.shape[0]), dtype=x2.dtype, device=x2.device) if need else None
+        h = ops.gemm_nt(x2, Wu, kind=EPI_GELU, C2=u)
+        y = ops.gemm_nt(h, Wd)
+        if need:
+            ctx.save_for_backward(u, Wu, Wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, Wu, Wd = ctx.saved_tensors
+        dy = dy.contiguous() if dy.dtype == u.dtype else dy.to(u.dtype).contiguous()
+        rows = dy.shape[0]
+        if ops.gemm_kmajor_supported(rows, Wd.shape[1], Wd.shape[0], dy.stride(0), Wd.stride(0), False, True, dy.dtype):
+            du = ops.gemm(dy, Wd, False, True, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+        else:
+            du = ops.gemm_nt(dy, ops.transpose(Wd, Wd.dtype), kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+        if ops.gemm_kmajor_supported(rows, Wu.shape[1], Wu.shape[0], du.stride(0), Wu.stride(0), False, True, du.dtype):
+            dx = ops.gemm(du, Wu, False, True)
+        else:
+            dx = ops.gemm_nt(du, ops.transpose(Wu, Wu.dtype))
+        return dx, None, None
+
+
+def frozen_mlp(x, Wu, Wd):
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    return FrozenMLPFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), Wu, Wd).view(shp[:-1] + (Wd.shape[0],))
+
+
+class FrozenLinearOwnFn(torch.autograd.Function):
+    """y = x W^T for a frozen bias-free Linear on csrc/gemm.hip; dx = dy W reads W as stored (K-major B operand)."""
+
+    @staticmethod
+    def forward(ctx, x2, W):
+        ctx.save_for_backward(W)
+        return ops.gemm_nt(x2, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (W,) = ctx.saved_tensors
+        dy = dy.contiguous() if dy.dtype == W.dtype else dy.to(W.dtype).contiguous()
+        if ops.gemm_kmajor_supported(dy.shape[0], W.shape[1], W.shape[0], dy.stride(0), W.stride(0), False, True, dy.dtype):
+            return ops.gemm(dy, W, False, True), None
+        return ops.gemm_nt(dy, ops.transpose(W, W.dtype)), None
+
+
+def frozen_linear_own(x, W):
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    return FrozenLinearOwnFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), W).view(shp[:-1] + (W.shape[0],))
+
+
 class SwiGLUFn(torch.autograd.Function):
     """h = silu(gate) * up on the fused [.., 2*I] gate|up projection output (xformers_model/llama.py:216-223), bf16."""
 

@@ -101,14 +101,14 @@ class _Norm(nn.LayerNorm):
         return OF.add_layer_norm(x, delta, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
 
 
-_OWN_GEMM = os.environ.get("OTTER_OWN_DECODER_GEMM") == "1"   # A/B hook: the frozen decoder's GEMMs on csrc/gemm.hip instead of hipBLASLt
+def _own_gemm() -> bool:
+    """OTTER_OWN_DECODER_GEMM=1: every GEMM of the frozen decoder on csrc/gemm.hip instead of hipBLASLt: fused
+    GELU / GELU' tails in the MLP (functional.FrozenMLPFn), input gradients against the weights as stored (K-major kernel: no transposed
+    copies).  Off by default: measured step time in DESIGN.md section 6 (the library's main loop is still ahead of ours in situ)."""
+    return os.environ.get("OTTER_OWN_DECODER_GEMM") == "1"
 
 
 def _lin(x, w):
-    if _OWN_GEMM and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16:
-        from . import ops
-        x2 = x.reshape(-1, x.shape[-1])
-        return ops.gemm_nt(x2 if x2.is_contiguous() else x2.contiguous(), w).view(x.shape[:-1] + (w.shape[0],))
     return F.linear(x, w)
 
 
@@ -141,9 +141,20 @@ class FrozenAwareLinear(nn.Linear):
             self._fz_w, self._fz_wt, self._fz_key = wc, wc.t().contiguous(), key
         return self._fz_w, self._fz_wt
 
+    def _copy_w(self, cd):
+        """The weight in the compute dtype only (own-kernel path: the input gradient reads it as stored, no transposed copy)."""
+        w = self.weight
+        if w.dtype == cd:
+            return w.detach()
+        key = (w._version, w.data_ptr(), cd)
+        if getattr(self, "_fzc_key", None) != key:
+            self._fzc_w, self._fzc_key = w.detach().to(cd), key
+        return self._fzc_w
+
     def release_copies(self):
         """Drop the cached compute-dtype / transposed copies (rebuilt on the next training forward)."""
         self._fz_w = self._fz_wt = self._fz_key = None
+        self._fzc_w = self._fzc_key = None
 
     def _apply(self, fn, *a, **k):
         # .to() / .cpu() / .half(): the copies would otherwise stay behind on the old device in the old dtype (ADVICE r2)
@@ -156,6 +167,8 @@ class FrozenAwareLinear(nn.Linear):
                 or os.environ.get("OTTER_NO_FROZEN_WT") == "1"):
             return F.linear(x, w, self.bias)
         cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        if _own_gemm() and cd == torch.bfloat16:
+            return OF.frozen_linear_own(x if x.dtype == cd else x.to(cd), self._copy_w(cd))
         wc, wt = self._copies(cd)
         return _FrozenLinearFn.apply(x if x.dtype == cd else x.to(cd), wc, wt)
 
@@ -168,6 +181,11 @@ class MPTMLP(nn.Module):
         self.down_proj = FrozenAwareLinear(expansion_ratio * d_model, d_model, bias=bias)
 
     def forward(self, x):
+        up, dn = self.up_proj, self.down_proj
+        if (_own_gemm() and x.is_cuda and up.bias is None and dn.bias is None and not up.weight.requires_grad and not dn.weight.requires_grad
+                and OF.compute_dtype_for(x) == torch.bfloat16):
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            return OF.frozen_mlp(xb, up._copy_w(torch.bfloat16), dn._copy_w(torch.bfloat16))
         u = self.up_proj(x)
         if u.is_cuda and os.environ.get("OTTER_TORCH_GELU") != "1":
             return self.down_proj(OF.gelu(u))      # csrc/elementwise.hip gelu_fwd / gelu_bwd (same exact-erf form as nn.GELU())
