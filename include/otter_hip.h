@@ -150,6 +150,11 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
 int otter_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc, int64_t M,
                int64_t N, int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream);
 int otter_gemm_kmajor_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int a_kmajor, int b_kmajor, int ab_dtype);
+/* Threading: every compute entry point of this header is asynchronous on the stream it is given and may be called concurrently from
+ * different host threads on DISTINCT streams (autograd's backward thread and the training thread do).  The otter_*_set_* switches below
+ * (variant, debug, CU budget, grid shape) and the otter_prof_* hooks are process-wide settings for tools, benchmarks and the training
+ * step's set-up phase: change them from one thread, between steps, never while another thread is launching.  The one-time
+ * hipFuncSetAttribute calls behind the first launch of each kernel are idempotent (a benign race). */
 /* selects the bf16 kernel schedule: 0 = auto, 1 = 128x128 register-staged, 2 = 256x256 register-staged,
  * 3 = 256x256 direct-to-LDS (global_load_lds).  Process-wide; for A/B measurements. */
 int otter_gemm_set_variant(int variant);
