@@ -95,6 +95,37 @@ shadows = _Shadows()
 grad_sink = None
 
 
+# Set by train.TrainStep: collects the SPARSE part of a tied embedding's gradient (the rows the input lookup touched) on the side, so
+# that the parameter's dense gradient -- the un-embedding product, the first thing backward computes -- is final, and reducible, right
+# away instead of after the very last node of the graph.  Interface: add(param, ids, drows); anchor (a 0-d tensor that requires grad).
+embed_sink = None
+
+
+class EmbedRowsFn(torch.autograd.Function):
+    """rows = weight[ids] with the gradient routed to `embed_sink` instead of to the parameter's autograd leaf (the weight enters detached;
+    the 0-d `anchor` only makes the output differentiable so that backward runs)."""
+
+    @staticmethod
+    def forward(ctx, anchor, ids, weight_data, holder):
+        ctx.ids, ctx.holder = ids, holder
+        return F.embedding(ids, weight_data)
+
+    @staticmethod
+    def backward(ctx, dout):
+        sink, param = ctx.holder
+        sink.add(param, ctx.ids, dout)
+        return None, None, None, None
+
+
+def embedding_rows(ids: torch.Tensor, weight: torch.nn.Parameter) -> torch.Tensor:
+    """F.embedding(ids, weight); with a live `embed_sink` (otter_amd's own TrainStep) the lookup's gradient is kept as (ids, rows) and
+    applied after backward -- see train.SparseEmbedSink.  Plain autograd (the reference's loop through the shim) is untouched."""
+    sink = embed_sink
+    if sink is not None and weight.requires_grad and torch.is_grad_enabled():
+        return EmbedRowsFn.apply(sink.anchor(weight.device), ids, weight.detach(), (sink, weight))
+    return F.embedding(ids, weight)
+
+
 def _wgrad(dyT: torch.Tensor, xT: torch.Tensor, gate=None, param=None):
     """dW[out,in] = (s *) dy^T . x   from the two transposed, zero-padded operands (fp32 result).  With a grad sink and
     `param`, the result lands in the sink's buffer and None is returned (autograd then has nothing to accumulate)."""

@@ -87,7 +87,7 @@ class SharedEmbedding(nn.Embedding):
                 # a 413 MB cast of the table every forward and a 826 MB cast of its gradient every backward (0.8 ms per step)
                 return OF.TrainableLinearFn.apply(input, self.weight, None)
             return F.linear(input, self.weight.to(input.dtype))
-        return super().forward(input)
+        return OF.embedding_rows(input, self.weight)    # F.embedding; under otter_amd's TrainStep the row gradients go to the sparse sink
 
 
 class _Norm(nn.LayerNorm):

@@ -168,6 +168,59 @@ def get_grouped_params(model: torch.nn.Module, wd: float):
     return [{"params": with_wd, "weight_decay": wd}, {"params": without_wd, "weight_decay": 0.0}]
 
 
+class SparseEmbedSink:
+    """The tied input/output embedding of the MPT host gets its gradient from two places: the un-embedding product (dense, 826 MB, the FIRST
+    thing backward computes) and the input lookup (4096 rows per rank, the LAST).  Stock autograd adds the two at the very end of backward:
+    a dense zero-fill + scatter + 826 MB add at N = 1 (0.6 ms), and -- worse -- the parameter's bucket cannot start its all-reduce before
+    backward is over (gap 4 of round 2).  With this sink (installed by TrainStep as functional.embed_sink) the lookup's
+    gradient stays (ids, rows): the dense part is final as soon as the loss has been differentiated and its all-reduce overlaps the whole
+    decoder backward; `apply()` then adds the rows -- after an all-gather of every rank's (ids, rows) at N > 1: 67 MB per rank instead of 826 MB
+    of un-hidden all-reduce."""
+
+    def __init__(self):
+        self.pending = []
+        self._anchor = {}
+
+    def anchor(self, device):
+        a = self._anchor.get(device)
+        if a is None:
+            a = torch.zeros((), device=device, requires_grad=True)
+            self._anchor[device] = a
+        return a
+
+    def add(self, param, ids, drows):
+        self.pending.append((param, ids.reshape(-1), drows.reshape(-1, drows.shape[-1])))
+
+    def apply(self, group=None, world: int = 1):
+        """grad[param] += (1 / world) * sum over ranks of scatter(ids, rows).  `world` > 1: every rank contributes its own (ids, rows)."""
+        pend, self.pending = self.pending, []
+        by_param = {}
+        for param, ids, rows in pend:
+            e = by_param.setdefault(id(param), [param, [], []])
+            e[1].append(ids)
+            e[2].append(rows)
+        for param, ids_l, rows_l in by_param.values():
+            ids = torch.cat(ids_l) if len(ids_l) > 1 else ids_l[0]
+            rows = torch.cat(rows_l) if len(rows_l) > 1 else rows_l[0]
+            if world > 1:
+                import torch.distributed as dist
+
+                n = torch.tensor([ids.numel()], device=ids.device, dtype=torch.int64)
+                dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)        # ragged batches (find_and_remove_tokens): pad to the longest
+                n_max = int(n.item())
+                if ids.numel() < n_max:                                       # padding adds zeros to row 0
+                    ids = torch.cat([ids, ids.new_zeros(n_max - ids.numel())])
+                    rows = torch.cat([rows, rows.new_zeros((n_max - rows.shape[0], rows.shape[1]))])
+                all_ids = [torch.empty_like(ids) for _ in range(world)]
+                all_rows = [torch.empty_like(rows) for _ in range(world)]
+                dist.all_gather(all_ids, ids.contiguous(), group=group)
+                dist.all_gather(all_rows, rows.contiguous(), group=group)
+                ids, rows = torch.cat(all_ids), torch.cat(all_rows)
+            if param.grad is None:
+                param.grad = torch.zeros_like(param)
+            param.grad.index_add_(0, ids, rows.to(param.grad.dtype), alpha=1.0 / world)
+
+
 def _lm_head_modules(model):
     """The modules `--mask_lm_head` touches, keyed on the language model's class name exactly like the reference
     (instruction_following.py:238-244)."""
@@ -215,6 +268,10 @@ class TrainStep:
                 raise ValueError("mask_lm_head needs answer_token_id")
             self.answer_token_id = int(answer_token_id)
             self.masked_embeddings = _lm_head_modules(model)
+        # the tied embedding's lookup gradient is collected sparsely (SparseEmbedSink); OTTER_DENSE_EMBED_GRAD=1 keeps stock autograd
+        self.embed_sink = None
+        if os.environ.get("OTTER_DENSE_EMBED_GRAD") != "1":
+            self.embed_sink = SparseEmbedSink()    # installed as functional.embed_sink only for the duration of a step (see __call__)
         row_only = {m.weight: self.answer_token_id for m in self.masked_embeddings if m.weight.requires_grad}
         # single rank: gradients stay ordinary .grad tensors (no bucket indirection, nothing to reduce)
         self.reducer = (GradReducer(self.params, bucket_bytes, process_group, force=force_reducer, row_only=row_only)
@@ -239,6 +296,7 @@ class TrainStep:
     def close(self):
         """Detach the DP reducer's autograd hooks and gradient sink (idempotent).  Call before building another TrainStep /
         GradReducer over the same model; also runs when the object is collected."""
+        self.embed_sink = None
         red, self.reducer = getattr(self, "reducer", None), None
         if red is not None:
             red.close()
@@ -270,19 +328,30 @@ class TrainStep:
             self.optimizer.zero_grad(set_to_none=True)
 
     def __call__(self, vision_x, input_ids, attention_mask, labels):
+        from . import functional as _F
+
         self.zero_grad()
         dev_type = input_ids.device.type
-        if self.autocast_dtype is not None:
-            with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
-                loss = self.model(vision_x=vision_x.to(self.autocast_dtype), lang_x=input_ids, attention_mask=attention_mask,
-                                  labels=labels)[0]
-        else:
-            loss = self.model(vision_x=vision_x, lang_x=input_ids, attention_mask=attention_mask, labels=labels)[0]
-        loss.backward()
+        sink = self.embed_sink
+        _F.embed_sink = sink          # only while THIS step's graph is built and differentiated: plain autograd users never see it
+        try:
+            if self.autocast_dtype is not None:
+                with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
+                    loss = self.model(vision_x=vision_x.to(self.autocast_dtype), lang_x=input_ids, attention_mask=attention_mask,
+                                      labels=labels)[0]
+            else:
+                loss = self.model(vision_x=vision_x, lang_x=input_ids, attention_mask=attention_mask, labels=labels)[0]
+            loss.backward()
+        finally:
+            _F.embed_sink = None
+        if sink is not None and (self.masked_embeddings or self.reducer is None or not self.reducer.sync):
+            sink.apply()                          # local: the mask below / the local accumulation needs the complete local gradient
         for m in self.masked_embeddings:          # before the reduction: the reducer then ships one row per masked tensor
             mask_embedding(m, self.answer_token_id)
         if self.reducer is not None:
             self.reducer.wait()
+            if sink is not None and sink.pending and self.reducer.sync:
+                sink.apply(self.reducer.group, self.world)   # rows of every rank, after the dense part has been averaged
         if self.max_grad_norm is not None and not self.hip_optimizer:
             torch.nn.utils.clip_grad_norm_(self.params, self.max_grad_norm)
         self.optimizer.step()   # the HIP optimizer clips inside its step

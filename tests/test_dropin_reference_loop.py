@@ -158,8 +158,11 @@ def test_reference_train_one_epoch_drives_otter_amd(ref_script, mask_lm_head, tm
             labels = TR.masking(ni["input_ids"], ans, twin.eoc_token_id, tok.encode(tok.eos_token)[-1])
             twin_losses.append(float(step(ni["patch_images"], ni["input_ids"], ni["attention_masks"], labels)))
     assert np.allclose(losses, twin_losses, rtol=1e-6, atol=0), (losses, twin_losses)
+    # (TrainStep adds the lookup rows of the tied embedding after the dense un-embedding gradient instead of as a second dense tensor: the
+    #  clipping coefficient moves in its last bit, and AdamW's m / (sqrt(v) + eps) turns that into up to lr * O(1e-3) on elements whose
+    #  gradient is of the order of eps -- hence the absolute term)
     for (n, a), (_, b) in zip(model.named_parameters(), twin.named_parameters()):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), n
+        assert torch.allclose(a, b, rtol=1e-5, atol=2e-6), (n, float((a - b).abs().max()))
     assert losses[1] != losses[0]
 
     # the reference's own checkpoint writer on the trained model == otter_amd.train's (same keys, same tensors)
