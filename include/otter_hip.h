@@ -145,7 +145,8 @@ int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* 
  * autograd's `grad_output.t().mm(input)`, the backward of every nn.Linear at otter/modeling_otter.py:140-147,254-256,366-368) and
  * dx = dy W with W as stored [out,in] (B K-major) -- so no operand is transposed in HBM first.  Same epilogues, dtypes and stream
  * semantics as otter_gemm_nt (which is this call with both flags 0).  Only shapes for which otter_gemm_kmajor_supported returns 1
- * are accepted (bf16, K % 128 == 0, >= 192 output tiles of 256 x 256, M / N / leading dimensions multiples of 8, operands < 4 GB);
+ * are accepted (bf16, K % 128 == 0 -- any K >= 128 when BOTH operands are K-major --, >= 192 output tiles of 256 x 256, M / N / leading
+ * dimensions multiples of 8, operands < 4 GB);
  * the host transposes (otter_transpose) and calls otter_gemm_nt otherwise. */
 int otter_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc, int64_t M,
                int64_t N, int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream);

@@ -2509,7 +2509,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     const bf16_t* __restrict__ A = (const bf16_t*)g.A;
     const bf16_t* __restrict__ B = (const bf16_t*)g.B;
-    const int nk = (int)(g.K >> 6);  // K-tiles (host guarantees nk even, nk >= 2)
+    // K-tiles (nk even, nk >= 2).  K-contiguous operands: the host guarantees K % 128 == 0.  BOTH operands K-major (the weight-gradient
+    // form): any K -- the K-tiles past the last row lie outside both descriptors and read as zeros, so the reduction is simply rounded up
+    const int nk = (TA && TB) ? (int)(((g.K + 127) >> 7) << 1) : (int)(g.K >> 6);
     const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
     // K-major operand: K rows of lda elements, M valid columns; rows past K are beyond num_records and read as zeros
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
@@ -3973,7 +3975,9 @@ int64_t otter_gemm_num_partials(int64_t M, int64_t N, int ab_dtype) {
 
 int otter_gemm_kmajor_supported(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int a_kmajor, int b_kmajor, int ab_dtype) {
     if (ab_dtype != OTTER_BF16 || g_variant != 0) return 0;
-    if (K % 128 != 0 || K < 128) return 0;                               // the register-resident K-tile pipeline (variant 26)
+    if (K < 128) return 0;
+    if (K % 128 != 0 && !(a_kmajor && b_kmajor)) return 0;               // K-contiguous operands: whole K-tile pairs (variant 26's pipeline);
+                                                                         // both K-major: any K (rows past K read as zeros)
     if (cdiv64(M, 256) * cdiv64(N, 256) < 192) return 0;                 // small grids run the ring kernel on K-contiguous operands
     if (a_kmajor && (M % 8 != 0 || lda % 8 != 0)) return 0;              // 16-byte chunks along the rows
     if (b_kmajor && (N % 8 != 0 || ldb % 8 != 0)) return 0;
@@ -3994,7 +3998,7 @@ int otter_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t 
                int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream) {
     if (a_kmajor || b_kmajor)
         OTTER_REQUIRE(otter_gemm_kmajor_supported(M, N, K, lda, ldb, a_kmajor, b_kmajor, ab_dtype),
-                      "gemm: K-major operands need bf16, K %% 128 == 0, >= 192 tiles of 256x256, M / N / ld %% 8 == 0 and < 4 GB per operand "
+                      "gemm: K-major operands need bf16, K %% 128 == 0 (any K when both are K-major), >= 192 tiles of 256x256, M / N / ld %% 8 == 0 and < 4 GB per operand "
                       "(M=%ld N=%ld K=%ld): ask otter_gemm_kmajor_supported first and transpose otherwise", (long)M, (long)N, (long)K);
     return gemm_impl(A, lda, a_kmajor ? 1 : 0, B, ldb, b_kmajor ? 1 : 0, C, ldc, M, N, K, ab_dtype, c_dtype, epi, stream);
 }
@@ -4004,8 +4008,8 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
     OTTER_REQUIRE(A && B && C && epi, "gemm: null pointer");
     OTTER_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty shape M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
     const int kal = ab_dtype == OTTER_BF16 ? 8 : 4;
-    OTTER_REQUIRE(K % kal == 0 && lda % kal == 0 && ldb % kal == 0, "gemm: K=%ld lda=%ld ldb=%ld must be multiples of %d",
-                  (long)K, (long)lda, (long)ldb, kal);
+    OTTER_REQUIRE(((a_kmajor && b_kmajor) || K % kal == 0) && lda % kal == 0 && ldb % kal == 0, "gemm: K=%ld lda=%ld ldb=%ld must be multiples of %d",
+                  (long)K, (long)lda, (long)ldb, kal);   // (both operands K-major: K is a row count, any value)
     OTTER_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "gemm: N=%ld ldc=%ld must be multiples of 4", (long)N, (long)ldc);
     OTTER_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm: 16-byte alignment");
     GemmArgs g;

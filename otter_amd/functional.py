@@ -934,10 +934,16 @@ class TrainableLinearFn(torch.autograd.Function):
         dx = torch.mm(dy2, shadows.w(W, torch.bfloat16)).view(ctx.shp) if ctx.needs_input_grad[0] else None
         dW = None
         if ctx.needs_input_grad[1]:
-            try:
-                dW = torch.mm(dy2.t(), x2, out_dtype=torch.float32)
-            except TypeError:  # older torch: no out_dtype
-                dW = torch.mm(dy2.t(), x2).float()
+            if (os.environ.get("OTTER_NO_KMAJOR") != "1" and dy2.is_cuda
+                    and ops.gemm_kmajor_supported(N, x2.shape[1], dy2.shape[0], dy2.stride(0), x2.stride(0), True, True, dy2.dtype)):
+                # round 3: dy^T x on the K-major kernel of csrc/gemm.hip -- both operands as they lie, fp32 out, any number of token rows
+                # (hipBLASLt's TN form with an fp32 output: 543-628 us at the FFN shapes against 386-394, tools/wgrad_paths.py)
+                dW = ops.gemm(dy2, x2, True, True, out_dtype=torch.float32)
+            else:
+                try:
+                    dW = torch.mm(dy2.t(), x2, out_dtype=torch.float32)
+                except TypeError:  # older torch: no out_dtype
+                    dW = torch.mm(dy2.t(), x2).float()
             dW = dW if dW.dtype == W.dtype else dW.to(W.dtype)
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
