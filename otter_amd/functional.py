@@ -931,7 +931,14 @@ class TrainableLinearFn(torch.autograd.Function):
         N = W.shape[0]
         dy2 = dy.reshape(-1, N)
         dy2 = (dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)).contiguous()
-        dx = torch.mm(dy2, shadows.w(W, torch.bfloat16)).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Wb = shadows.w(W, torch.bfloat16)
+            if (os.environ.get("OTTER_NO_KMAJOR") != "1" and os.environ.get("OTTER_NO_KMAJOR_DGRAD") != "1" and dy2.is_cuda
+                    and ops.gemm_kmajor_supported(dy2.shape[0], Wb.shape[1], N, dy2.stride(0), Wb.stride(0), False, True, dy2.dtype)):
+                dx = ops.gemm(dy2, Wb, False, True).view(ctx.shp)      # dy W with W as stored = the K-major B operand (hipBLASLt's NN form is its slow one)
+            else:
+                dx = torch.mm(dy2, Wb).view(ctx.shp)
         dW = None
         if ctx.needs_input_grad[1]:
             if (os.environ.get("OTTER_NO_KMAJOR") != "1" and dy2.is_cuda
