@@ -419,7 +419,7 @@ def main():
             v = args.gemm_variant or 26
             names = {13: "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves, phased)", 18: "gemm_bf16_r4_kernel (256x256x64 tile, 4 waves, register-resident K-tile)",
                      26: "gemm_bf16_t4_kernel (256x256x64 tile, 4 waves, register-resident K-tile, 16x16x32 MFMA)"}
-            pmc = os.path.join(ROOT, "profiles", {18: "r02_pmc_gemm_ffn_v18.json", 26: "r02_pmc_gemm_ffn_v26.json"}.get(v, "r01_pmc_gemm_ffn_v13.json"))
+            pmc = os.path.join(ROOT, "profiles", {18: "r02_pmc_gemm_ffn_v18.json", 26: "r03_pmc_gemm_ffn_traffic.json"}.get(v, "r01_pmc_gemm_ffn_v13.json"))
             if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
                 with open(pmc) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
