@@ -321,8 +321,11 @@ class MPTModel(MPTPreTrainedModel):
 
     def _flash_spec(self, x, s_past: int, attention_mask):
         """(alibi slopes [H] fp32, key_valid [B,S] uint8 or None) when the HIP flash-attention kernel covers this call:
-        bf16 compute on the GPU, head_dim 128, no KV cache to prepend, no left padding (a fully masked query row comes
-        out as the uniform average in the reference and as 0 in the kernel).  Otherwise None -> additive-mask SDPA path."""
+        bf16 compute on the GPU, head_dim 128, no KV cache to prepend.  Left padding: a fully masked query row (a pad position) comes
+        out as the uniform average of V in the reference and as 0 in the kernel.  Those rows only ever feed the keys / values of their own
+        positions, which every real query masks -- the hidden states and logits of the real tokens are identical -- so an inference pass
+        (generate()'s left-padded prompt, no autograd) takes the kernel too (round 3); under autograd the additive-mask SDPA path stays,
+        because the gradient that reaches pad rows differs.  Otherwise None -> SDPA."""
         if not x.is_cuda or s_past != 0 or not self.is_causal or OF.compute_dtype_for(x) != torch.bfloat16:
             return None
         if self.config.d_model // self.config.n_heads != 128 or os.environ.get("OTTER_NO_FLASH") == "1":
@@ -331,7 +334,7 @@ class MPTModel(MPTPreTrainedModel):
         if attention_mask is not None:
             am = attention_mask.bool()
             if not bool(am.all()):
-                if not bool(am[:, 0].all()):
+                if not bool(am[:, 0].all()) and torch.is_grad_enabled():
                     return None
                 key_valid = am.to(torch.uint8).contiguous()
         if self._slopes is None or self._slopes.device != x.device:
