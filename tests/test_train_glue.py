@@ -139,3 +139,36 @@ def test_trainable_only_checkpoints_roundtrip(tmp_path):
     torch.save(blob, tmp_path / "short.pt")
     with pytest.raises(KeyError, match="does not cover"):
         TR.load_trained_ckpt(other, str(tmp_path / "short.pt"))
+
+
+def test_bench_self_spawns_its_ranks(monkeypatch):
+    """Driver contract: `python bench.py --gpus N` without WORLD_SIZE must not die -- it re-launches itself under
+    torch.distributed.run with one rank per GPU on 127.0.0.1 and hands its arguments through."""
+    import importlib
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and os.path.basename(cmd[-7]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # inside a torchrun launch a mismatch between --gpus and WORLD_SIZE is an error, not a silent single-GPU run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="WORLD_SIZE"):
+        bench.main()
