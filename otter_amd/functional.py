@@ -907,6 +907,53 @@ def scatter_patch_rows(word, patch, idx):
     return ScatterPatchRowsFn.apply(word, patch, idx)
 
 
+_SPAN_LIMIT = (1 << 32) - (1 << 20)   # the K-major kernel addresses its operands with 32-bit byte offsets
+
+
+def _kmajor_wgrad_any_size(dy2, x2):
+    """dW = dy^T x (fp32) on the K-major kernel, with the token rows cut into chunks when an operand spans 4 GB or more (Fuyu's 262144-row
+    vocabulary: dy is 5.9 GB): the first chunk stores, the others accumulate.  None when the shape does not qualify."""
+    rows, n_out = dy2.shape
+    n_in = x2.shape[1]
+    span = max(dy2.stride(0), x2.stride(0)) * 2 * rows
+    parts = 1 if span < _SPAN_LIMIT else -(-span // (_SPAN_LIMIT - (1 << 28)))
+    step = -(-rows // parts)
+    step = -(-step // 128) * 128
+    if not ops.gemm_kmajor_supported(n_out, n_in, min(step, rows), dy2.stride(0), x2.stride(0), True, True, dy2.dtype):
+        return None
+    cuts = [(r0, min(r0 + step, rows)) for r0 in range(0, rows, step)]
+    if any(r1 - r0 < 128 for r0, r1 in cuts):      # (a tail shorter than one K-tile pair: leave the whole product to the library)
+        return None
+    dW = torch.empty((n_out, n_in), dtype=torch.float32, device=dy2.device)
+    for i, (r0, r1) in enumerate(cuts):
+        ops.gemm(dy2[r0:r1], x2[r0:r1], True, True, out=dW, kind=EPI_STORE, accumulate=(i > 0))
+    return dW
+
+
+def _kmajor_dgrad_any_size(dy2, Wb):
+    """dx = dy W (W stored [out, in] = the K-major B operand), dy cut into row blocks when it spans 4 GB or more.  None when unsupported."""
+    rows, n_out = dy2.shape
+    n_in = Wb.shape[1]
+    if Wb.stride(0) * 2 * n_out >= _SPAN_LIMIT:
+        return None
+    span = dy2.stride(0) * 2 * rows
+    parts = 1 if span < _SPAN_LIMIT else -(-span // (_SPAN_LIMIT - (1 << 28)))
+    step = -(-rows // parts)
+    step = -(-step // 256) * 256
+    if not ops.gemm_kmajor_supported(min(step, rows), n_in, n_out, dy2.stride(0), Wb.stride(0), False, True, dy2.dtype):
+        return None
+    if parts == 1:
+        return ops.gemm(dy2, Wb, False, True)
+    dx = torch.empty((rows, n_in), dtype=dy2.dtype, device=dy2.device)
+    for r0 in range(0, rows, step):
+        r1 = min(r0 + step, rows)
+        if not ops.gemm_kmajor_supported(r1 - r0, n_in, n_out, dy2.stride(0), Wb.stride(0), False, True, dy2.dtype):
+            torch.mm(dy2[r0:r1], Wb, out=dx[r0:r1])      # a short last block (< 192 tiles)
+        else:
+            ops.gemm(dy2[r0:r1], Wb, False, True, out=dx[r0:r1])
+    return dx
+
+
 class TrainableLinearFn(torch.autograd.Function):
     """y = x W^T + b for a TRAINABLE nn.Linear under bf16 compute with fp32 masters (every Linear of the fully fine-tuned Fuyu
     decoder): the bf16 operand copy of W is the cached shadow that FusedAdamW refreshes inside its own update pass (autocast
@@ -934,19 +981,16 @@ class TrainableLinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             Wb = shadows.w(W, torch.bfloat16)
-            if (os.environ.get("OTTER_NO_KMAJOR") != "1" and os.environ.get("OTTER_NO_KMAJOR_DGRAD") != "1" and dy2.is_cuda
-                    and ops.gemm_kmajor_supported(dy2.shape[0], Wb.shape[1], N, dy2.stride(0), Wb.stride(0), False, True, dy2.dtype)):
-                dx = ops.gemm(dy2, Wb, False, True).view(ctx.shp)      # dy W with W as stored = the K-major B operand (hipBLASLt's NN form is its slow one)
-            else:
-                dx = torch.mm(dy2, Wb).view(ctx.shp)
+            dx = None
+            if os.environ.get("OTTER_NO_KMAJOR") != "1" and os.environ.get("OTTER_NO_KMAJOR_DGRAD") != "1" and dy2.is_cuda:
+                dx = _kmajor_dgrad_any_size(dy2, Wb)     # dy W with W as stored = the K-major B operand (hipBLASLt's NN form is its slow one)
+            dx = (dx if dx is not None else torch.mm(dy2, Wb)).view(ctx.shp)
         dW = None
         if ctx.needs_input_grad[1]:
-            if (os.environ.get("OTTER_NO_KMAJOR") != "1" and dy2.is_cuda
-                    and ops.gemm_kmajor_supported(N, x2.shape[1], dy2.shape[0], dy2.stride(0), x2.stride(0), True, True, dy2.dtype)):
-                # round 3: dy^T x on the K-major kernel of csrc/gemm.hip -- both operands as they lie, fp32 out, any number of token rows
-                # (hipBLASLt's TN form with an fp32 output: 543-628 us at the FFN shapes against 386-394, tools/wgrad_paths.py)
-                dW = ops.gemm(dy2, x2, True, True, out_dtype=torch.float32)
-            else:
+            # round 3: dy^T x on the K-major kernel of csrc/gemm.hip -- both operands as they lie, fp32 out, any number of token rows
+            # (hipBLASLt's TN form with an fp32 output: 543-628 us at the FFN shapes against 386-394, tools/wgrad_paths.py)
+            dW = _kmajor_wgrad_any_size(dy2, x2) if (os.environ.get("OTTER_NO_KMAJOR") != "1" and dy2.is_cuda) else None
+            if dW is None:
                 try:
                     dW = torch.mm(dy2.t(), x2, out_dtype=torch.float32)
                 except TypeError:  # older torch: no out_dtype
