@@ -223,7 +223,8 @@ int otter_attn_bwd(const void* q, int64_t q_stride, const void* k, const void* v
                    int64_t Tq, int64_t M, int64_t n_per_media, int mask_mode, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
- * Flash attention of the frozen decoder host, head_dim 128, bf16, MFMA:
+ * Flash attention of the frozen decoder host, head_dim 128 -- and, round 3, head_dim 64 (Persimmon / Fuyu-8B,
+ * /root/reference/src/otter_ai/models/fuyu/modeling_persimmon.py:310 flash_attn_func(causal=True)) --, bf16, MFMA:
  *   scaled_multihead_dot_product_attention   /root/reference/src/otter_ai/models/mpt/attention.py:22-84
  *   ALiBi bias (key-position form)           .../mpt/attention.py:447-464      bias[h,j] = slope[h] * (j - (Sk-1))
  *   key-padding mask                         .../mpt/modeling_mpt.py:135-144
@@ -235,6 +236,9 @@ int otter_attn_bwd(const void* q, int64_t q_stride, const void* k, const void* v
  * 2*B*H*Sq floats (row dot products, then a log2-domain copy of lse).  A query row with no visible key yields 0 (lse = -inf) and zero gradients; the reference's
  * masked_fill(finfo.min) would yield the uniform average there -- such rows only exist for left-padded prompts,
  * which the host routes to its SDPA path.
+ * head_dim 64: one workgroup takes two adjacent heads (H must be even); the second head of a pair lies head_stride elements after
+ * the first inside the same token row (64 <= head_stride <= seq_stride - 64), so compact [B,S,H,64] tensors and the v slots of
+ * Persimmon's per-head interleaved [B,S,H,3,64] projection buffer (head_stride 192) are both read / written in place.
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct otter_flash_view {
     int64_t batch_stride, seq_stride, head_stride; /* in elements; multiples of 8 */
@@ -256,7 +260,7 @@ typedef struct otter_flash_desc {
 
 int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream);
 /* tuning / A-B hook: 0 = default (LDS-DMA tiles, longest-first block order under the causal mask), 1 = register-staged tiles (v1),
- * 2 = LDS-DMA tiles on the plain 3-D grid, 3 / 5 = 2 / 0 with dK+dV at two workgroups per CU, 4 = 0 */
+ * 2 = LDS-DMA tiles on the plain 3-D grid, 3 / 5 = 2 / 0 with dK+dV at two workgroups per CU, 4 = 0 (head_dim 64: 1 is refused, 3 / 5 = 2 / 0) */
 int otter_flash_set_variant(int variant);
 int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream);
 
@@ -318,9 +322,11 @@ int otter_decode_attn(const void* q, int64_t q_batch_stride, int64_t q_head_stri
  *   otter_qk_norm_rope_fwd  /root/reference/src/otter_ai/models/fuyu/modeling_persimmon.py:262-304: the per-head interleaved
  *       projection output qkv [tokens, H, 3, 64] (bf16) is read in place; q and k get LayerNorm over the 64-wide head
  *       (gamma / beta fp32 [64]) and the partial rotary embedding on their first `rot` dims (cos / sin fp32 [S, rot], position
- *       = token % S); q', k', v are written as bf16 [tokens, H, 128] with columns 64..127 zero (head-dim padding for the
- *       128-wide flash kernels).  stats [tokens, H, 2, 2] fp32 = (mean, rstd) of q and k, for the backward.
- *   otter_qk_norm_rope_bwd  dq / dk / dv [tokens, H, 128] (columns 0..63 used) -> dqkv [tokens, H, 3, 64]; partial
+ *       = token % S); q', k' (and v unless v_out is NULL: the head_dim-64 attention kernels read v in place from qkv) are written
+ *       as bf16 [tokens, H, out_width]: out_width 64 = compact heads, 128 = columns 64..127 zero (head-dim padding for the
+ *       128-wide flash kernels, round 2's layout).  stats [tokens, H, 2, 2] fp32 = (mean, rstd) of q and k, for the backward.
+ *   otter_qk_norm_rope_bwd  dq / dk / dv [tokens, H, in_width] (columns 0..63 used) -> dqkv [tokens, H, 3, 64]; dv NULL: the v slots
+ *       of dqkv are left alone (the attention backward wrote them in place); partial
  *       [otter_qk_norm_rope_bwd_blocks(tokens, H), 4, 64] fp32 = per-block sums of (dgamma_q, dbeta_q, dgamma_k, dbeta_k),
  *       to be summed over the first axis by the caller (deterministic).
  *   otter_sqrelu_fwd/_bwd   relu(x)^2 (:180-194), bf16, n % 8 == 0.
@@ -328,11 +334,11 @@ int otter_decode_attn(const void* q, int64_t q_batch_stride, int64_t q_head_stri
  * ------------------------------------------------------------------------------------------------------- */
 int otter_qk_norm_rope_fwd(const void* qkv, const float* gamma_q, const float* beta_q, const float* gamma_k, const float* beta_k,
                            const float* cos_t, const float* sin_t, void* q_out, void* k_out, void* v_out, float* stats, int64_t tokens,
-                           int64_t S, int64_t H, int64_t rot, float eps, void* stream);
+                           int64_t S, int64_t H, int64_t rot, float eps, int64_t out_width, void* stream);
 int64_t otter_qk_norm_rope_bwd_blocks(int64_t tokens, int64_t H);
 int otter_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv, const float* stats, const float* gamma_q,
                            const float* gamma_k, const float* cos_t, const float* sin_t, void* dqkv, float* partial, int64_t tokens,
-                           int64_t S, int64_t H, int64_t rot, void* stream);
+                           int64_t S, int64_t H, int64_t rot, int64_t in_width, void* stream);
 int otter_sqrelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int otter_sqrelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
 int otter_scatter_rows(const void* word, int word_dtype, const void* patch, int patch_dtype, const int64_t* idx, void* out, int64_t B,

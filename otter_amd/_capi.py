@@ -107,9 +107,9 @@ SIGNATURES = {
     "otter_flash_set_variant": (_int, [_int]),
     "otter_decode_attn": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64,
                                  _i64, _f32, _vp]),
-    "otter_qk_norm_rope_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "otter_qk_norm_rope_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _i64, _vp]),
     "otter_qk_norm_rope_bwd_blocks": (_i64, [_i64, _i64]),
-    "otter_qk_norm_rope_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "otter_qk_norm_rope_bwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp]),
     "otter_sqrelu_fwd": (_int, [_vp, _vp, _i64, _vp]),
     "otter_sqrelu_bwd": (_int, [_vp, _vp, _vp, _i64, _vp]),
     "otter_scatter_rows": (_int, [_vp, _int, _vp, _int, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),

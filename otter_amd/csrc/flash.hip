@@ -21,6 +21,7 @@
 // for their access pattern: 16 rows x one 16-B slot, resp. 4 rows x 64 B per 32 lanes); a tile needed both ways is
 // stored twice.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -49,7 +50,8 @@ struct FlashArgs {
     const bf16_t* dout; Str dos;
     float* delta;          // [B, H, Sq]
     bf16_t* dq; bf16_t* dk; bf16_t* dv; Str dqs, dks, dvs;
-    int lpt_group;         // heads per group of the longest-first block order (divides B*H)
+    int lpt_group;         // heads (PAIR: head pairs) per group of the longest-first block order (divides the number of (b, head) blocks)
+    int pair;              // head_dim 64: two heads per workgroup (the PAIR instantiations)
 };
 
 // In-kernel timeline of workgroup (3,0,0) / wave 0 of the forward (diagnostics build only: -DOTTER_FLASH_TIMING)
@@ -122,6 +124,22 @@ __device__ __forceinline__ void store_dt(bf16_t* rowp, const f32x16_t (&acc)[4],
             w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
             *reinterpret_cast<uint2*>(rowp + 32 * db + 8 * g + 4 * h2) = w;
         }
+}
+
+// head-pair form (see "head pairs" below): d blocks 0-1 belong to the first head of the pair (scaled by mul0), blocks 2-3 to the second
+// (mul1), whose 64 columns start `poff` + 64 elements after the first head's
+__device__ __forceinline__ void store_dt_pair(bf16_t* rowp, const f32x16_t (&acc)[4], float mul0, float mul1, int h2, int64_t poff) {
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const float mul = db < 2 ? mul0 : mul1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
+            w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(rowp + 32 * db + 8 * g + 4 * h2 + (db >= 2 ? poff : 0)) = w;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -324,7 +342,17 @@ __device__ __forceinline__ void flash_dma_tile(u32x4_t rk, u32x4_t rv, char* kds
     }
 }
 
-template <bool LPT>
+// Head pairs (PAIR, head_dim 64: Persimmon / Fuyu-8B, fuyu/modeling_persimmon.py:310): one workgroup takes TWO heads whose 64-wide rows
+// lie head_stride elements apart in the same token.  The 256-B LDS row of a tile holds head A's 64 columns in slots 0-7 and head B's in
+// slots 8-15 (only the DMA source offset of a slot changes), so every tile layout, swizzle and fragment address of the 128-wide kernel
+// stays; the contraction over d splits into c = 0-3 (head A) and c = 4-7 (head B), the softmax runs once per head, and d blocks 0-1 /
+// 2-3 of the second product take P of head A / B.  Against zero-padding the heads to 128 (round 2): half the MFMA work, half the tile
+// traffic and workgroups, no padded q / k / v / o / dO copies.  a.H counts real heads; a pair block is (b, hd) with hd < H/2.
+// The pair kernels have ONE tile code path: every tile applies its visibility mask (one 64-bit word per lane, v_bfe_i32 + v_bfi_b32 per
+// score).  Separate interior / masked paths as in the 128-wide kernels did not fit the 256 registers of two workgroups per CU (84-392 B of
+// scratch per lane, reloaded through VMEM in front of every tile) and measured slower, as did one workgroup per CU with 512 registers
+// (C5 shape, forward / backward: 142 / 451 us one path, 153 / 650 two paths, 196 / 505 one workgroup per CU; zero-padded heads 205 / 694).
+template <bool LPT, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
@@ -332,18 +360,21 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     // LPT: 1-D grid, LAST query tile first (under the causal mask it sees the most keys): the launch ends on the short blocks
     const int nqb = (a.Sq + 127) >> 7;
     const LptIdx li = lpt_decode((int)blockIdx.x, nqb, a.lpt_group);
-    const int b = LPT ? li.bh / a.H : blockIdx.z, hd = LPT ? li.bh % a.H : blockIdx.y;
+    const int HB = PAIR ? a.H >> 1 : a.H, hm = PAIR ? 2 : 1;   // head blocks per batch row; heads per block
+    const int b = LPT ? li.bh / HB : blockIdx.z, hd = LPT ? li.bh % HB : blockIdx.y;
     const int q0 = (LPT ? nqb - 1 - li.rank : (int)blockIdx.x) * 128;
     const int qi = q0 + wave * 32 + ql;
     const int off = a.Sk - a.Sq;
-    const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)(qi < a.Sq ? qi : a.Sq - 1) * a.qs.s;
+    const bf16_t* qp = a.q + b * a.qs.b + hd * hm * a.qs.h + (int64_t)(qi < a.Sq ? qi : a.Sq - 1) * a.qs.s;
+    const int64_t qpo = PAIR ? a.qs.h - 64 : 0;   // extra element offset of columns 64.. (head B)
     bf16x8_t qf[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2);
-    const bf16_t* kb = a.k + b * a.ks.b + hd * a.ks.h;
-    const bf16_t* vb = a.v + b * a.vs.b + hd * a.vs.h;
+    for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2 + (c >= 4 ? qpo : 0));
+    const bf16_t* kb = a.k + b * a.ks.b + hd * hm * a.ks.h;
+    const bf16_t* vb = a.v + b * a.vs.b + hd * hm * a.vs.h;
     const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
-    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd * hm] * LOG2E : 0.f;
+    const float sl2b = PAIR && a.slopes ? a.slopes[hd * 2 + 1] * LOG2E : 0.f;
     int nkt = (a.Sk + 63) >> 6;
     if (a.causal) {
         const int qmax = (q0 + 127 < a.Sq ? q0 + 127 : a.Sq - 1) + off;
@@ -351,14 +382,16 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         nkt = nkt < lim ? nkt : lim;
     }
     const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
-    const u32x4_t rk = make_rsrc4(kb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u)));
-    const u32x4_t rv = make_rsrc4(vb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u)));
+    const uint32_t kpb = PAIR ? (uint32_t)((a.ks.h - 64) * 2) : 0u, vpb = PAIR ? (uint32_t)((a.vs.h - 64) * 2) : 0u;   // source bytes skipped before slot 8
+    const u32x4_t rk = make_rsrc4(kb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u + kpb)));
+    const u32x4_t rv = make_rsrc4(vb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u + vpb)));
     uint32_t vk[4], vv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rl = 4 * (wave * 4 + i) + (lane >> 4), p = lane & 15;
-        vk[i] = (uint32_t)rl * krow + (uint32_t)((p ^ (rl & 15)) << 4);
-        vv[i] = (uint32_t)rl * vrow + (uint32_t)(((((p >> 2) ^ (rl & 3)) << 2) | (p & 3)) << 4);
+        const int sk = p ^ (rl & 15), sv = (((p >> 2) ^ (rl & 3)) << 2) | (p & 3);   // source slot that lands in LDS slot p
+        vk[i] = (uint32_t)rl * krow + (uint32_t)(sk << 4) + (sk >= 8 ? kpb : 0u);
+        vv[i] = (uint32_t)rl * vrow + (uint32_t)(sv << 4) + (sv >= 8 ? vpb : 0u);
     }
     // read side: K row fragment of row 32 kbk + ql, logical slot 2c + h2 -> byte ((32c) ^ (y << 4)) with y = h2 ^ (ql & 15);
     // V transpose read: lane i of a 16-lane group supplies row 4h + (i>>2) (+ key base, + 8), d block db at 64-B block
@@ -367,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     const int gi = lane & 15, gg = lane >> 4;
     const int vto = (4 * (gg >> 1) + (gi >> 2)) * 256 + ((gi >> 2) << 6) + 32 * (gg & 1) + 8 * (gi & 3);
     float m = -INFINITY, lsum = 0.f;
+    float mB = -INFINITY, lsumB = 0.f;   // PAIR: statistics of head B
     f32x16_t o[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = zero16();
@@ -404,6 +438,95 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         if (a.causal && k0 > wq0 + 31) continue;  // whole tile above this wave's diagonal
         const char* Kc = smem + cur * 16384;
         const char* Vc = smem + 32768 + cur * 16384;
+        if constexpr (PAIR) {
+            // visibility of the lane's 32 keys of the tile as one bit mask (bit cidx): causal / sequence-end limit and key-padding bits
+            unsigned okm_lo, okm_hi;
+            {
+                const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
+                const int limh = (a.causal && rel < kend ? rel : kend) - 4 * h2;
+                unsigned long long vmh = ~0ull;
+                if (kmask_lds) {
+                    vmh = kmask[kt] >> (4 * h2);
+                } else if (kv) {
+                    const int jj = k0 + lane;
+                    vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
+                }
+                const unsigned long long okm = limh < 0 ? 0ull : (limh >= 63 ? vmh : vmh & ((2ull << limh) - 1ull));
+                okm_lo = (unsigned)okm;
+                okm_hi = (unsigned)(okm >> 32);
+            }
+            // one head's share of the tile (E: std::integral_constant, the head's register indices must be compile-time)
+            auto head = [&](auto E) {
+                constexpr int e = decltype(E)::value;
+                f32x16_t sp[2];
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk) {
+                    sp[kbk] = zero16();
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        sp[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            *reinterpret_cast<const bf16x8_t*>(Kc + kbk * 8192 + (kfo ^ (32 * (c + 4 * e)))), qf[c + 4 * e], sp[kbk], 0, 0, 0);
+                }
+                const float sle = e ? sl2b : sl2;
+                float& me = e ? mB : m;
+                float& le = e ? lsumB : lsum;
+                const float base = sle * (float)(k0 + 4 * h2 - (a.Sk - 1));
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                        float x = fmaf(sp[kbk][r], sc2, fmaf(sle, (float)cidx, base));
+                        {   // v_bfe_i32 + v_bfi_b32: 0 / ~0 from the key's bit, then x or -inf
+                            const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)(cidx < 32 ? okm_lo : okm_hi), cidx & 31, 1);
+                            x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, x) & mk) | (~mk & 0xFF800000u));
+                        }
+                        sp[kbk][r] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (__ballot(mx > me + 8.0f) != 0ull) {
+                    const float mnew = fmaxf(me, mx);
+                    const float muse = mnew == -INFINITY ? 0.f : mnew;
+                    const float alpha = __builtin_amdgcn_exp2f(me - muse);
+                    me = mnew;
+                    le *= alpha;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[2 * e + db][r] *= alpha;
+                }
+                const float muse = me == -INFINITY ? 0.f : me;
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(sp[kbk][r] - muse);
+                        sp[kbk][r] = p;
+                        le += p;
+                    }
+#pragma unroll
+                for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const bf16x8_t pf = pack8(sp[kbk], 8 * c);
+#pragma unroll
+                        for (int dbl = 0; dbl < 2; ++dbl) {
+                            const int db = 2 * e + dbl;
+                            const char* tp = Vc + (vto ^ (db << 6)) + (32 * kbk + 16 * c) * 256;
+                            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)tp);
+                            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tp + 2048));
+                            const s16x8_t vfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vfr), pf, o[db], 0, 0, 0);
+                        }
+                    }
+            };
+            head(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);   // heads apart: interleaved, both heads' score registers are live at once
+            head(std::integral_constant<int, 1>{});
+            continue;
+        }
         f32x16_t s[2];
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
@@ -493,6 +616,19 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     FSTAMP(90);
     lsum += __shfl_xor(lsum, 32, 64);
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    if constexpr (PAIR) {
+        lsumB += __shfl_xor(lsumB, 32, 64);
+        const float invB = lsumB > 0.f ? 1.0f / lsumB : 0.f;
+        if (qi < a.Sq) {
+            store_dt_pair(a.o + b * a.os.b + hd * 2 * a.os.h + (int64_t)qi * a.os.s, o, inv, invB, h2, a.os.h - 64);
+            if (h2 == 0) {
+                float* lp = a.lse + ((int64_t)b * a.H + hd * 2) * a.Sq + qi;
+                lp[0] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
+                lp[a.Sq] = lsumB > 0.f ? mB * LN2 + logf(lsumB) : -INFINITY;
+            }
+        }
+        return;
+    }
     if (qi < a.Sq) {
         store_dt(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s, o, inv, h2);
         if (h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
@@ -508,9 +644,10 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
 // ------------------------------------------------------------------------------------------------------------
 // delta[b,h,q] = sum_d dO . O   (16 lanes per row)
 // ------------------------------------------------------------------------------------------------------------
+template <int LPR>   // lanes per row: head_dim / 8
 __global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
-    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int c = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + (threadIdx.x / LPR);
+    const int c = threadIdx.x & (LPR - 1);
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
     float acc = 0.f;
     if (row < nrows) {
@@ -524,7 +661,7 @@ __global__ __launch_bounds__(256) void flash_delta_kernel(FlashArgs a) {
         for (int i = 0; i < 8; ++i) acc += x[i] * y[i];
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (row < nrows && c == 0) {
         a.delta[row] = acc;
         const float l = a.lse[row];
@@ -788,33 +925,37 @@ __device__ __forceinline__ bf16x8_t tr_pi_frag(const char* tile, int o1, int o2,
     return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <bool LPT>
+template <bool LPT, bool PAIR = false>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqb = (a.Sq + 127) >> 7;   // LPT: see flash_fwd2_kernel
     const LptIdx li = lpt_decode((int)blockIdx.x, nqb, a.lpt_group);
-    const int b = LPT ? li.bh / a.H : blockIdx.z, hd = LPT ? li.bh % a.H : blockIdx.y;
+    const int HB = PAIR ? a.H >> 1 : a.H, hm = PAIR ? 2 : 1;
+    const int b = LPT ? li.bh / HB : blockIdx.z, hd = LPT ? li.bh % HB : blockIdx.y;
     const int q0 = (LPT ? nqb - 1 - li.rank : (int)blockIdx.x) * 128;
     const int qi = q0 + wave * 32 + ql;
     const int qc = qi < a.Sq ? qi : a.Sq - 1;
     const int off = a.Sk - a.Sq;
-    const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)qc * a.qs.s;
-    const bf16_t* dop = a.dout + b * a.dos.b + hd * a.dos.h + (int64_t)qc * a.dos.s;
+    const bf16_t* qp = a.q + b * a.qs.b + hd * hm * a.qs.h + (int64_t)qc * a.qs.s;
+    const bf16_t* dop = a.dout + b * a.dos.b + hd * hm * a.dos.h + (int64_t)qc * a.dos.s;
+    const int64_t qpo = PAIR ? a.qs.h - 64 : 0, dopo = PAIR ? a.dos.h - 64 : 0;
     bf16x8_t qf[8], dof[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2);
-        dof[c] = *reinterpret_cast<const bf16x8_t*>(dop + 16 * c + 8 * h2);
+        qf[c] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * c + 8 * h2 + (c >= 4 ? qpo : 0));
+        dof[c] = *reinterpret_cast<const bf16x8_t*>(dop + 16 * c + 8 * h2 + (c >= 4 ? dopo : 0));
     }
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
-    const int64_t srow = ((int64_t)b * a.H + hd) * a.Sq + qc;
+    const int64_t srow = ((int64_t)b * a.H + hd * hm) * a.Sq + qc;
     const float lse2 = qi < a.Sq ? a.delta[nrows + srow] : INFINITY, dl = a.delta[srow];
-    const bf16_t* kb = a.k + b * a.ks.b + hd * a.ks.h;
-    const bf16_t* vb = a.v + b * a.vs.b + hd * a.vs.h;
+    const float lse2B = PAIR ? (qi < a.Sq ? a.delta[nrows + srow + a.Sq] : INFINITY) : 0.f, dlB = PAIR ? a.delta[srow + a.Sq] : 0.f;
+    const bf16_t* kb = a.k + b * a.ks.b + hd * hm * a.ks.h;
+    const bf16_t* vb = a.v + b * a.vs.b + hd * hm * a.vs.h;
     const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
-    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd * hm] * LOG2E : 0.f;
+    const float sl2B = PAIR && a.slopes ? a.slopes[hd * 2 + 1] * LOG2E : 0.f;
     int nkt = (a.Sk + 63) >> 6;
     if (a.causal) {
         const int qmax = (q0 + 127 < a.Sq ? q0 + 127 : a.Sq - 1) + off;
@@ -822,14 +963,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
         nkt = nkt < lim ? nkt : lim;
     }
     const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
-    const u32x4_t rk = make_rsrc4(kb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u)));
-    const u32x4_t rv = make_rsrc4(vb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u)));
+    const uint32_t kpb = PAIR ? (uint32_t)((a.ks.h - 64) * 2) : 0u, vpb = PAIR ? (uint32_t)((a.vs.h - 64) * 2) : 0u;
+    const u32x4_t rk = make_rsrc4(kb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u + kpb)));
+    const u32x4_t rv = make_rsrc4(vb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u + vpb)));
     uint32_t vk[4], vv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rl = 4 * (wave * 4 + i) + (lane >> 4), p = lane & 15;
-        vk[i] = (uint32_t)rl * krow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
-        vv[i] = (uint32_t)rl * vrow + (uint32_t)((p ^ (rl & 15)) << 4);
+        const int sk = p ^ pi16(rl & 15), sv = p ^ (rl & 15);
+        vk[i] = (uint32_t)rl * krow + (uint32_t)(sk << 4) + (sk >= 8 ? kpb : 0u);
+        vv[i] = (uint32_t)rl * vrow + (uint32_t)(sv << 4) + (sv >= 8 ? vpb : 0u);
     }
     const int kfo = ql * 256 + ((h2 ^ pi16(ql & 15)) << 4);
     const int vfo = ql * 256 + ((h2 ^ (ql & 15)) << 4);
@@ -879,6 +1022,44 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
             const int jj = k0 + lane;
             vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
         }
+        if constexpr (PAIR) {
+            // bit cidx: the lane's key cidx of the tile is visible (one code path for interior and masked tiles: see the forward)
+            const unsigned long long okm = limh < 0 ? 0ull : (limh >= 63 ? vmh : vmh & ((2ull << limh) - 1ull));
+            const unsigned okm_lo = (unsigned)okm, okm_hi = (unsigned)(okm >> 32);
+            auto part = [&](auto KBK, auto E) {
+                constexpr int kbk = decltype(KBK)::value, e = decltype(E)::value;
+                f32x16_t s = zero16(), dp = zero16();
+#pragma unroll
+                for (int c = 4 * e; c < 4 * e + 4; ++c) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Kc + kbk * 8192 + (kfo ^ (32 * c))), qf[c], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Vc + kbk * 8192 + (vfo ^ (32 * c))), dof[c], dp, 0, 0, 0);
+                }
+                const float sle = e ? sl2B : sl2, dle = e ? dlB : dl;
+                const float be = sle * (float)(k0 + 4 * h2 - (a.Sk - 1)) - (e ? lse2B : lse2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, fmaf(sle, (float)cidx, be)));
+                    const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)(cidx < 32 ? okm_lo : okm_hi), cidx & 31, 1);
+                    p = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) & mk);
+                    s[r] = p * (dp[r] - dle);
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bf16x8_t dsf = pack8(s, 8 * c);
+#pragma unroll
+                    for (int dbl = 0; dbl < 2; ++dbl)
+                        dq[2 * e + dbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Kc, to1, to2, 2 * e + dbl, 32 * kbk + 16 * c), dsf,
+                                                                                  dq[2 * e + dbl], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one (key block, head) at a time: interleaved, the kernel outgrows its 256 registers
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            part(I0{}, I0{}); part(I0{}, I1{});
+            part(I1{}, I0{}); part(I1{}, I1{});
+            continue;
+        }
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
             f32x16_t s = zero16(), dp = zero16();
@@ -912,10 +1093,14 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
             }
         }
     }
+    if constexpr (PAIR) {
+        if (qi < a.Sq) store_dt_pair(a.dq + b * a.dqs.b + hd * 2 * a.dqs.h + (int64_t)qi * a.dqs.s, dq, a.scale, a.scale, h2, a.dqs.h - 64);
+        return;
+    }
     if (qi < a.Sq) store_dt(a.dq + b * a.dqs.b + hd * a.dqs.h + (int64_t)qi * a.dqs.s, dq, a.scale, h2);
 }
 
-template <int MINB, bool LPT>
+template <int MINB, bool LPT, bool PAIR = false>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
 __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) {
     // 3-stage ring, two query tiles in flight (a 32-row tile is only ~1k MFMA cycles of work, less than the DMA latency):
     // Q[3] | dO[3] (8 KB each) | lse2[3][64] | delta[3][64]
@@ -926,27 +1111,30 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     // LPT: 1-D grid walked key block by key block -- under the causal mask key block 0 has the most query tiles, so the longest blocks
     // are dispatched first and the launch ends on the short ones
     const LptIdx li = lpt_decode((int)blockIdx.x, (a.Sk + 127) >> 7, a.lpt_group);
-    const int b = LPT ? li.bh / a.H : blockIdx.z, hd = LPT ? li.bh % a.H : blockIdx.y;
+    const int HB = PAIR ? a.H >> 1 : a.H, hm = PAIR ? 2 : 1;
+    const int b = LPT ? li.bh / HB : blockIdx.z, hd = LPT ? li.bh % HB : blockIdx.y;
     const int k0 = (LPT ? li.rank : (int)blockIdx.x) * 128;
     const int kw = k0 + wave * 32, kj = kw + ql;
     const int off = a.Sk - a.Sq;
     const int kc = kj < a.Sk ? kj : a.Sk - 1;
-    const bf16_t* kp = a.k + b * a.ks.b + hd * a.ks.h + (int64_t)kc * a.ks.s;
-    const bf16_t* vp = a.v + b * a.vs.b + hd * a.vs.h + (int64_t)kc * a.vs.s;
+    const bf16_t* kp = a.k + b * a.ks.b + hd * hm * a.ks.h + (int64_t)kc * a.ks.s;
+    const bf16_t* vp = a.v + b * a.vs.b + hd * hm * a.vs.h + (int64_t)kc * a.vs.s;
+    const int64_t kpo = PAIR ? a.ks.h - 64 : 0, vpo = PAIR ? a.vs.h - 64 : 0;
     bf16x8_t kf[8], vf[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        kf[c] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * c + 8 * h2);
-        vf[c] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * c + 8 * h2);
+        kf[c] = *reinterpret_cast<const bf16x8_t*>(kp + 16 * c + 8 * h2 + (c >= 4 ? kpo : 0));
+        vf[c] = *reinterpret_cast<const bf16x8_t*>(vp + 16 * c + 8 * h2 + (c >= 4 ? vpo : 0));
     }
     bool kok = kj < a.Sk;
     if (a.kvalid) kok = kok && a.kvalid[(int64_t)b * a.Sk + kc] != 0;
-    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd * hm] * LOG2E : 0.f;
     const float bias2 = sl2 * (float)(kj - (a.Sk - 1));
-    const bf16_t* qb = a.q + b * a.qs.b + hd * a.qs.h;
-    const bf16_t* dob = a.dout + b * a.dos.b + hd * a.dos.h;
+    const float bias2B = PAIR && a.slopes ? a.slopes[hd * 2 + 1] * LOG2E * (float)(kj - (a.Sk - 1)) : 0.f;
+    const bf16_t* qb = a.q + b * a.qs.b + hd * hm * a.qs.h;
+    const bf16_t* dob = a.dout + b * a.dos.b + hd * hm * a.dos.h;
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
-    const float* dlb = a.delta + ((int64_t)b * a.H + hd) * a.Sq;
+    const float* dlb = a.delta + ((int64_t)b * a.H + hd * hm) * a.Sq;
     const float* lsb = dlb + nrows;
     const int nqt = (a.Sq + 31) >> 5;
     int qt0 = 0;
@@ -955,16 +1143,21 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         qt0 = imin > 0 ? (imin >> 5) : 0;
     }
     const uint32_t qrow = (uint32_t)(a.qs.s * 2), dorow = (uint32_t)(a.dos.s * 2);
-    const u32x4_t rq = make_rsrc4(qb, (uint32_t)((int)((uint32_t)(a.Sq - 1) * qrow + 256u)));
-    const u32x4_t rdo = make_rsrc4(dob, (uint32_t)((int)((uint32_t)(a.Sq - 1) * dorow + 256u)));
-    const u32x4_t rls = make_rsrc4(lsb, (uint32_t)(a.Sq * 4));
-    const u32x4_t rdl = make_rsrc4(dlb, (uint32_t)(a.Sq * 4));
+    const uint32_t qpb = PAIR ? (uint32_t)((a.qs.h - 64) * 2) : 0u, dpb = PAIR ? (uint32_t)((a.dos.h - 64) * 2) : 0u;
+    const u32x4_t rq = make_rsrc4(qb, (uint32_t)((int)((uint32_t)(a.Sq - 1) * qrow + 256u + qpb)));
+    const u32x4_t rdo = make_rsrc4(dob, (uint32_t)((int)((uint32_t)(a.Sq - 1) * dorow + 256u + dpb)));
+    // PAIR: the statistics words of a tile are lanes 0-31 = head A's 32 rows, lanes 32-63 = head B's (the next row of the [B,H,Sq] arrays);
+    // head A's rows past Sq then read head B's first words instead of zeros: finite (delta) or +inf (log2 lse of a dead row), and masked
+    const u32x4_t rls = make_rsrc4(lsb, (uint32_t)(a.Sq * 4 * hm));
+    const u32x4_t rdl = make_rsrc4(dlb, (uint32_t)(a.Sq * 4 * hm));
+    const uint32_t stat_voff = PAIR ? (uint32_t)((lane & 31) * 4 + (lane >> 5) * a.Sq * 4) : (uint32_t)lane * 4u;
     uint32_t vq[2], vd[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rl = 4 * (wave * 2 + i) + (lane >> 4), p = lane & 15;
-        vq[i] = (uint32_t)rl * qrow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
-        vd[i] = (uint32_t)rl * dorow + (uint32_t)((p ^ pi16(rl & 15)) << 4);
+        const int sq = p ^ pi16(rl & 15);
+        vq[i] = (uint32_t)rl * qrow + (uint32_t)(sq << 4) + (sq >= 8 ? qpb : 0u);
+        vd[i] = (uint32_t)rl * dorow + (uint32_t)(sq << 4) + (sq >= 8 ? dpb : 0u);
     }
     char* const stat = smem + 49152;
     auto issue = [&](int qt, int buf) {
@@ -974,8 +1167,8 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
             dma16_asm(rdo, smem + 24576 + buf * 8192 + (wave * 2 + i) * 1024, vd[i], (uint32_t)qt * 32u * dorow);
         }
         if (wave == 0) {  // 64 floats each (the upper 32 belong to the next tile; rows past Sq read as 0 and are masked)
-            dma4_asm(rls, stat + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
-            dma4_asm(rdl, stat + 768 + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
+            dma4_asm(rls, stat + buf * 256, stat_voff, (uint32_t)qt * 128u);
+            dma4_asm(rdl, stat + 768 + buf * 256, stat_voff, (uint32_t)qt * 128u);
         }
     };
     const int qfo = ql * 256 + ((h2 ^ pi16(ql & 15)) << 4);
@@ -1019,8 +1212,8 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
             if (p & 1) dma16_asm(rdo, smem + 24576 + buf * 8192 + (wave * 2 + i) * 1024, vd[i], (uint32_t)qt * 32u * dorow);
             else dma16_asm(rq, smem + buf * 8192 + (wave * 2 + i) * 1024, vq[i], (uint32_t)qt * 32u * qrow);
         } else {
-            if (p == 4) dma4_asm(rls, stat + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
-            else dma4_asm(rdl, stat + 768 + buf * 256, (uint32_t)lane * 4u, (uint32_t)qt * 128u);
+            if (p == 4) dma4_asm(rls, stat + buf * 256, stat_voff, (uint32_t)qt * 128u);
+            else dma4_asm(rdl, stat + 768 + buf * 256, stat_voff, (uint32_t)qt * 128u);
         }
     };
     // dK / dV MFMAs through asm with AGPR accumulators ("+a"); s_nop 1 covers a VALU-written (cvt_pk) B operand; the _MEM form also orders
@@ -1042,6 +1235,131 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         // used.  Guarding each piece / read on qt+2 < nqt cost 19 scalar branches + ~40 scalar ALU instructions per iteration, and with one
         // wave per SIMD every instruction, scalar or not, is an issue slot of four cycles.
         const int nb = cur == 0 ? 2 : cur - 1;   // slot of tile qt-1 = slot of tile qt+2
+        if constexpr (PAIR) {
+            // Same pipeline, one head after the other inside the tile: per head 8 S / dP MFMAs (c = 4e .. 4e+3) with that head's eight
+            // transpose-read fragments (d blocks 2e, 2e+1) and -- head A -- the DMA pieces of tile qt+2 between them, the softmax (rows 8-15
+            // one stage per dV / dK MFMA of the first half), then the four second-half MFMAs; head B's carry the row-fragment reads of tile
+            // qt+1 behind the mid-iteration barrier.  The visibility window (lo, hi) is the same for both heads.
+            const bool interior = i0 + 31 < a.Sq && (!a.causal || kw + 31 <= i0 + off);  // wave-uniform
+            int lo = 0, hi = 32;
+            if (!interior) {
+                const int vis = a.causal ? kj - off - i0 : 0;
+                lo = vis > 0 ? vis : 0;
+                hi = a.Sq - i0 < 32 ? a.Sq - i0 : 32;
+            }
+            if (!kok) hi = 0;
+            const unsigned span = hi > lo ? (unsigned)(hi - lo) : 0u;
+            const int idx0 = 4 * h2 - lo;
+            const int nx = cur == 2 ? 0 : cur + 1;
+            const char* Qn = smem + nx * 8192;
+            const char* Dn = smem + 24576 + nx * 8192;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float bias_e = e ? bias2B : bias2;
+                bf16x8_t tD[2][2], tQ[2][2];
+                f32x16_t s, dp;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int c = 4 * e + c4;
+                    if (c4 == 0) {
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(qr[c]), "v"(kf[c]));
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(dp) : "v"(dr[c]), "v"(vf[c]));
+                    } else {
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(qr[c]), "v"(kf[c]));
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(dp) : "v"(dr[c]), "v"(vf[c]));
+                    }
+                    {
+                        const int cc = c4 >> 1;
+                        if ((c4 & 1) == 0) {
+                            tD[cc][0] = tr_pi_frag(Dc, to1, to2, 2 * e, 16 * cc);
+                            tD[cc][1] = tr_pi_frag(Dc, to1, to2, 2 * e + 1, 16 * cc);
+                        } else {
+                            tQ[cc][0] = tr_pi_frag(Qc, to1, to2, 2 * e, 16 * cc);
+                            tQ[cc][1] = tr_pi_frag(Qc, to1, to2, 2 * e + 1, 16 * cc);
+                        }
+                    }
+                    if (e == 0) issue_piece(qt + 2, nb, c4);
+                    else if (c4 == 0 && wave == 0) { issue_piece(qt + 2, nb, 4); issue_piece(qt + 2, nb, 5); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s), "+v"(dp));
+#define DKV_ELEM(R_, LV_, DV_)                                                                         \
+    do {                                                                                               \
+        const float pe_ = __builtin_amdgcn_exp2f(fmaf(s[R_], sc2, bias_e - (LV_)));                     \
+        const bool ok_ = (unsigned)(idx0 + 8 * ((R_) >> 2) + ((R_) & 3)) < span;                       \
+        const float p_ = ok_ ? pe_ : 0.f;                                                              \
+        s[R_] = p_;                                                                                    \
+        dp[R_] = p_ * (dp[R_] - (DV_));                                                                \
+    } while (0)
+                {
+                    float lv[8], dvv[8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 32 * e + 8 * g + 4 * h2);
+                        const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 32 * e + 8 * g + 4 * h2);
+                        lv[4 * g] = l4.x; lv[4 * g + 1] = l4.y; lv[4 * g + 2] = l4.z; lv[4 * g + 3] = l4.w;
+                        dvv[4 * g] = d4.x; dvv[4 * g + 1] = d4.y; dvv[4 * g + 2] = d4.z; dvv[4 * g + 3] = d4.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) DKV_ELEM(r, lv[r], dvv[r]);
+                }
+#undef DKV_ELEM
+                const bf16x8_t pf0 = pack8(s, 0), dsf0 = pack8(dp, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    float lv[8], dvv[8], t[8];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + 32 * e + 8 * (g + 2) + 4 * h2);
+                        const float4 d4 = *reinterpret_cast<const float4*>(dl_s + 32 * e + 8 * (g + 2) + 4 * h2);
+                        lv[4 * g] = l4.x; lv[4 * g + 1] = l4.y; lv[4 * g + 2] = l4.z; lv[4 * g + 3] = l4.w;
+                        dvv[4 * g] = d4.x; dvv[4 * g + 1] = d4.y; dvv[4 * g + 2] = d4.z; dvv[4 * g + 3] = d4.w;
+                    }
+#define PIN8() asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]))
+                    asm volatile("" : "+v"(s), "+v"(dp));
+                    MFMA_ACC(dv[2 * e], tD[0][0], pf0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = fmaf(s[8 + j], sc2, bias_e - lv[j]);
+                    PIN8();
+                    MFMA_ACC(dk[2 * e], tQ[0][0], dsf0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = __builtin_amdgcn_exp2f(t[j]);
+                    PIN8();
+                    MFMA_ACC(dv[2 * e + 1], tD[0][1], pf0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) t[j] = (unsigned)(idx0 + 8 * ((8 + j) >> 2) + (j & 3)) < span ? t[j] : 0.f;
+                    PIN8();
+                    MFMA_ACC(dk[2 * e + 1], tQ[0][1], dsf0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        s[8 + j] = t[j];
+                        dp[8 + j] = t[j] * (dp[8 + j] - dvv[j]);
+                    }
+#undef PIN8
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const bf16x8_t pf1 = pack8(s, 8), dsf1 = pack8(dp, 8);
+                if (e == 1) {
+                    if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i & 1) MFMA_ACC_MEM(dk[2 * e + (i >> 1)], tQ[1][i >> 1], dsf1);
+                    else MFMA_ACC_MEM(dv[2 * e + (i >> 1)], tD[1][i >> 1], pf1);
+                    if (e == 1) {
+                        qr[2 * i] = *reinterpret_cast<const bf16x8_t*>(Qn + (qfo ^ (32 * (2 * i))));
+                        dr[2 * i] = *reinterpret_cast<const bf16x8_t*>(Dn + (qfo ^ (32 * (2 * i))));
+                        qr[2 * i + 1] = *reinterpret_cast<const bf16x8_t*>(Qn + (qfo ^ (32 * (2 * i + 1))));
+                        dr[2 * i + 1] = *reinterpret_cast<const bf16x8_t*>(Dn + (qfo ^ (32 * (2 * i + 1))));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            continue;
+        }
         // ---- phase 1: S^T / dP^T (16 MFMAs, VGPR accumulators through asm: see below).  Every MFMA pair is followed by its share of the
         // other work of the iteration -- two transpose-read fragments of THIS tile (needed in phase 3) and one DMA piece of tile qt+2 --
         // and a sched_barrier pins that order: one wave per SIMD issues in order, so anything issued in a burst (48 LDS reads, 4-6 DMA
@@ -1196,6 +1514,13 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     // the accumulators were last written by asm MFMAs hipcc knows nothing about: 18+ wait states before it reads them out of the AGPRs
     asm volatile("s_nop 15\n\ts_nop 3" : "+a"(dk[0]), "+a"(dk[1]), "+a"(dk[2]), "+a"(dk[3]), "+a"(dv[0]), "+a"(dv[1]), "+a"(dv[2]), "+a"(dv[3]));
     DSTAMP(90);
+    if constexpr (PAIR) {
+        if (kj < a.Sk) {
+            store_dt_pair(a.dk + b * a.dks.b + hd * 2 * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, a.scale, h2, a.dks.h - 64);
+            store_dt_pair(a.dv + b * a.dvs.b + hd * 2 * a.dvs.h + (int64_t)kj * a.dvs.s, dv, 1.0f, 1.0f, h2, a.dvs.h - 64);
+        }
+        return;
+    }
     if (kj < a.Sk) {
         store_dt(a.dk + b * a.dks.b + hd * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, h2);
         store_dt(a.dv + b * a.dvs.b + hd * a.dvs.h + (int64_t)kj * a.dvs.s, dv, 1.0f, h2);
@@ -1210,8 +1535,10 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
 
 int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
     OTTER_REQUIRE(d && d->q && d->k && d->v && d->o && d->lse, "flash: null pointer");
-    OTTER_REQUIRE(d->head_dim == HD, "flash: head_dim %d (only 128)", d->head_dim);
+    OTTER_REQUIRE(d->head_dim == HD || d->head_dim == 64, "flash: head_dim %d (128, or 64 with an even number of heads)", d->head_dim);
     OTTER_REQUIRE(d->B > 0 && d->H > 0 && d->Sq > 0 && d->Sk > 0, "flash: empty shape");
+    const bool pair = d->head_dim == 64;
+    OTTER_REQUIRE(!pair || d->H % 2 == 0, "flash: head_dim 64 runs two heads per workgroup and needs an even head count (got %d)", d->H);
     const otter_flash_view* vs[] = {&d->qv, &d->kv, &d->vv, &d->ov, &d->dov, &d->dqv, &d->dkv, &d->dvv};
     for (int i = 0; i < (bwd ? 8 : 4); ++i)
         OTTER_REQUIRE(vs[i]->batch_stride % 8 == 0 && vs[i]->seq_stride % 8 == 0 && vs[i]->head_stride % 8 == 0,
@@ -1223,9 +1550,14 @@ int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
     a.qs = st(d->qv); a.ks = st(d->kv); a.vs = st(d->vv); a.os = st(d->ov);
     a.lse = d->lse; a.slopes = d->alibi_slopes; a.kvalid = d->key_valid;
     a.B = d->B; a.H = d->H; a.Sq = d->Sq; a.Sk = d->Sk; a.causal = d->causal; a.scale = d->scale;
-    {   // heads per LPT group: the K + V (= Q + dO) panels of a group, Sk x 128 x 2 B x 2 per head, within 64 MB; a divisor of B*H and a
-        // multiple of 8 when there is one (blocks are dealt round-robin to the 8 XCDs: same head -> same XCD), else one group
-        const int64_t nbh = (int64_t)d->B * d->H, per_head = (int64_t)(d->Sk > d->Sq ? d->Sk : d->Sq) * 512;
+    a.pair = pair ? 1 : 0;
+    if (pair) {   // the second head of a pair must lie inside the first head's token row, after its 64 columns
+        for (int i = 0; i < (bwd ? 8 : 4); ++i)
+            OTTER_REQUIRE(vs[i]->head_stride >= 64 && vs[i]->head_stride + 64 <= vs[i]->seq_stride, "flash: head_dim 64 wants 64 <= head_stride <= seq_stride - 64");
+    }
+    {   // heads per LPT group: the K + V (= Q + dO) panels of a group, Sk x 128 x 2 B x 2 per head (or head pair), within 64 MB; a divisor
+        // of the block count and a multiple of 8 when there is one (blocks are dealt round-robin to the 8 XCDs: same head -> same XCD)
+        const int64_t nbh = (int64_t)d->B * (pair ? d->H / 2 : d->H), per_head = (int64_t)(d->Sk > d->Sq ? d->Sk : d->Sq) * 512;
         int64_t g = nbh;
         const int64_t cap = (int64_t(64) << 20) / (per_head > 0 ? per_head : 1);
         if (g > cap) {
@@ -1274,7 +1606,19 @@ int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
     if (rc) return rc;
     // the DMA path addresses a head's K / V with 32-bit offsets from its base
     const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < (int64_t(1) << 31) && (int64_t)a.Sk * a.vs.s * 2 < (int64_t(1) << 31);
-    if (v2) {
+    OTTER_REQUIRE(v2 || !a.pair, "flash: head_dim 64 only on the LDS-DMA kernels (variant != 1, K / V panels under 2 GB)");
+    if (v2 && a.pair) {
+        const int smem = 65536 + KMASK_TILES * 8;
+        static bool once = false;
+        if (!once) {
+            rc = set_smem(flash_fwd2_kernel<false, true>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<true, true>, smem); if (rc) return rc;
+            once = true;
+        }
+        const unsigned nqb = (unsigned)((a.Sq + 127) / 128), hb = (unsigned)(a.H / 2);
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, true>), dim3(nqb * hb * a.B), dim3(256), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((flash_fwd2_kernel<false, true>), dim3(nqb, hb, a.B), dim3(256), smem, (hipStream_t)stream, a);
+    } else if (v2) {
 #ifdef OTTER_FLASH_TIMING
         const int smem = 65536 + KMASK_TILES * 8 + 1024;
 #else
@@ -1282,13 +1626,13 @@ int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
 #endif
         static bool once = false;
         if (!once) {
-            rc = set_smem(flash_fwd2_kernel<false>, smem); if (rc) return rc;
-            rc = set_smem(flash_fwd2_kernel<true>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<false, false>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<true, false>, smem); if (rc) return rc;
             once = true;
         }
         const unsigned nqb = (unsigned)((a.Sq + 127) / 128);
-        if (flash_lpt(a)) hipLaunchKernelGGL(flash_fwd2_kernel<true>, dim3(nqb * a.H * a.B), dim3(256), smem, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(flash_fwd2_kernel<false>, dim3(nqb, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, false>), dim3(nqb * a.H * a.B), dim3(256), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((flash_fwd2_kernel<false, false>), dim3(nqb, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
     } else {
         const int smem = 64 * LDK * 2 + 64 * LDT * 2;
         static bool once = false;
@@ -1305,11 +1649,32 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
-    hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, st, a);
+    if (a.pair) hipLaunchKernelGGL(flash_delta_kernel<8>, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(flash_delta_kernel<16>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, st, a);
     OTTER_CHECK_LAUNCH("flash_delta");
     const int64_t lim = int64_t(1) << 31;
     const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < lim && (int64_t)a.Sk * a.vs.s * 2 < lim &&
                     (int64_t)a.Sq * a.qs.s * 2 < lim && (int64_t)a.Sq * a.dos.s * 2 < lim;
+    OTTER_REQUIRE(v2 || !a.pair, "flash: head_dim 64 only on the LDS-DMA kernels (variant != 1, panels under 2 GB)");
+    if (v2 && a.pair) {
+        const int smem_kv = 49152 + 1536, smem_q = 65536 + KMASK_TILES * 8;
+        static bool once = false;
+        if (!once) {
+            rc = set_smem(flash_bwd_dkv2_kernel<1, false, true>, smem_kv); if (rc) return rc;
+            rc = set_smem(flash_bwd_dkv2_kernel<1, true, true>, smem_kv); if (rc) return rc;
+            rc = set_smem(flash_bwd_dq2_kernel<false, true>, smem_q); if (rc) return rc;
+            rc = set_smem(flash_bwd_dq2_kernel<true, true>, smem_q); if (rc) return rc;
+            once = true;
+        }
+        const unsigned nkb = (unsigned)((a.Sk + 127) / 128), nqb = (unsigned)((a.Sq + 127) / 128), hb = (unsigned)(a.H / 2);
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, true>), dim3(nkb * hb * a.B), dim3(256), smem_kv, st, a);
+        else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, true>), dim3(nkb, hb, a.B), dim3(256), smem_kv, st, a);
+        OTTER_CHECK_LAUNCH("flash_bwd_dkv");
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
+        else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
+        OTTER_CHECK_LAUNCH("flash_bwd_dq");
+        return OTTER_OK;
+    }
     if (v2) {
         #ifdef OTTER_FLASH_TIMING
         const int smem_kv = 49152 + 1536 + 1024, smem_q = 65536 + KMASK_TILES * 8;
@@ -1318,23 +1683,23 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
 #endif
         static bool once = false;
         if (!once) {
-            rc = set_smem(flash_bwd_dkv2_kernel<1, false>, smem_kv); if (rc) return rc;
-            rc = set_smem(flash_bwd_dkv2_kernel<2, false>, smem_kv); if (rc) return rc;
-            rc = set_smem(flash_bwd_dkv2_kernel<1, true>, smem_kv); if (rc) return rc;
-            rc = set_smem(flash_bwd_dkv2_kernel<2, true>, smem_kv); if (rc) return rc;
-            rc = set_smem(flash_bwd_dq2_kernel<false>, smem_q); if (rc) return rc;
-            rc = set_smem(flash_bwd_dq2_kernel<true>, smem_q); if (rc) return rc;
+            rc = set_smem(flash_bwd_dkv2_kernel<1, false, false>, smem_kv); if (rc) return rc;
+            rc = set_smem(flash_bwd_dkv2_kernel<2, false, false>, smem_kv); if (rc) return rc;
+            rc = set_smem(flash_bwd_dkv2_kernel<1, true, false>, smem_kv); if (rc) return rc;
+            rc = set_smem(flash_bwd_dkv2_kernel<2, true, false>, smem_kv); if (rc) return rc;
+            rc = set_smem((flash_bwd_dq2_kernel<false, false>), smem_q); if (rc) return rc;
+            rc = set_smem((flash_bwd_dq2_kernel<true, false>), smem_q); if (rc) return rc;
             once = true;
         }
         const unsigned nkb = (unsigned)((a.Sk + 127) / 128);
-        if (g_flash_variant == 3) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
-        else if (flash_lpt(a) && g_flash_variant != 5) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
-        else if (g_flash_variant == 5 && a.causal) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, true>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
-        else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
+        if (g_flash_variant == 3) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
+        else if (flash_lpt(a) && g_flash_variant != 5) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
+        else if (g_flash_variant == 5 && a.causal) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
+        else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
         OTTER_CHECK_LAUNCH("flash_bwd_dkv");
         const unsigned nqb = (unsigned)((a.Sq + 127) / 128);
-        if (flash_lpt(a)) hipLaunchKernelGGL(flash_bwd_dq2_kernel<true>, dim3(nqb * a.H * a.B), dim3(256), smem_q, st, a);
-        else hipLaunchKernelGGL(flash_bwd_dq2_kernel<false>, dim3(nqb, a.H, a.B), dim3(256), smem_q, st, a);
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, false>), dim3(nqb * a.H * a.B), dim3(256), smem_q, st, a);
+        else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, false>), dim3(nqb, a.H, a.B), dim3(256), smem_q, st, a);
         OTTER_CHECK_LAUNCH("flash_bwd_dq");
         return OTTER_OK;
     }

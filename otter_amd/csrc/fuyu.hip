@@ -2,8 +2,10 @@
 // All HBM-bound; 16-byte vectors; bf16 storage, fp32 arithmetic.
 //   otter_qk_norm_rope_fwd/_bwd  q/k LayerNorm over head_dim 64 (fuyu/modeling_persimmon.py:285-287, flash-attn's fused_layer_norm),
 //                                partial rotary on the first `rot` dims (:290-304), read IN PLACE from the per-head interleaved
-//                                [tokens, H, 3, 64] projection buffer (_split_heads :262-275), written as [tokens, H, 128] with
-//                                the upper 64 columns zero (head-dim padding for csrc/flash.hip's 128-wide kernels: exact).
+//                                [tokens, H, 3, 64] projection buffer (_split_heads :262-275), written as compact [tokens, H, 64]
+//                                heads for csrc/flash.hip's head-pair kernels (v is then read in place: no copy; round 3), or --
+//                                round 2's layout, kept for odd head counts and A/B runs -- as [tokens, H, 128] with the upper 64
+//                                columns zero (head-dim padding for the 128-wide kernels: exact).
 //   otter_sqrelu_fwd/_bwd        relu(x)^2 of the MLP (:180-194, fused_mlp_func "sqrelu")
 //   otter_scatter_rows           patch embeddings into the word-embedding sequence (fuyu/modeling_fuyu.py:44-77)
 #include "common.h"
@@ -40,6 +42,9 @@ __device__ __forceinline__ void rope8(float (&x)[8], const float* __restrict__ c
     }
 }
 
+// NSEL = 3: q, k and v vectors (v copied); 2: q and k only (the attention kernels read v in place from the projection buffer).
+// PDW = 128: outputs zero-padded to 128 columns; 64: compact [tokens, H, 64]
+template <int NSEL, int PDW>
 __global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ gq, const float* __restrict__ bq,
                                                              const float* __restrict__ gk, const float* __restrict__ bk,
                                                              const float* __restrict__ cs, const float* __restrict__ sn, bf16_t* __restrict__ qo,
@@ -50,12 +55,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const bf16_t* __r
     const int l8 = threadIdx.x & 7;
     const bool live = vec < nvec;
     const int64_t vc = live ? vec : nvec - 1;
-    const int sel = (int)(vc % 3);
-    const int64_t th = vc / 3;                       // token * H + head
+    const int sel = (int)(vc % NSEL);
+    const int64_t th = vc / NSEL;                    // token * H + head
     const int64_t tok = th / H;
     float x[8];
-    Vec8<bf16_t>::load(qkv + vc * HD + 8 * l8, x);
-    bf16_t* out = (sel == 0 ? qo : sel == 1 ? ko : vo) + th * PD;
+    Vec8<bf16_t>::load(qkv + (th * 3 + sel) * HD + 8 * l8, x);
+    bf16_t* out = (sel == 0 ? qo : sel == 1 ? ko : vo) + th * PDW;
     if (sel < 2) {
         float sum = 0.f;
 #pragma unroll
@@ -77,10 +82,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const bf16_t* __r
     }
     if (live) {
         Vec8<bf16_t>::store(out + 8 * l8, x);
-        *reinterpret_cast<uint4*>(out + HD + 8 * l8) = make_uint4(0, 0, 0, 0);
+        if (PDW == PD) *reinterpret_cast<uint4*>(out + HD + 8 * l8) = make_uint4(0, 0, 0, 0);
     }
 }
 
+template <int NSEL, int PDW>   // NSEL = 2: the attention backward has already written the v slots of dqkv
 __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk, const bf16_t* __restrict__ dv,
                                                              const bf16_t* __restrict__ qkv, const float* __restrict__ stats,
                                                              const float* __restrict__ gq, const float* __restrict__ gk, const float* __restrict__ cs,
@@ -96,14 +102,14 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const bf16_t* __r
         const int64_t vec = v0 + it + grp;
         const bool live = vec < nvec && it + grp < vec_per_block;
         const int64_t vc = live ? vec : (nvec - 1);
-        const int sel = (int)(vc % 3);
-        const int64_t th = vc / 3, tok = th / H;
+        const int sel = (int)(vc % NSEL);
+        const int64_t th = vc / NSEL, tok = th / H;
         float dy[8];
-        Vec8<bf16_t>::load((sel == 0 ? dq : sel == 1 ? dk : dv) + th * PD + 8 * l8, dy);
+        Vec8<bf16_t>::load((sel == 0 ? dq : sel == 1 ? dk : dv) + th * PDW + 8 * l8, dy);
         if (sel < 2) {
             rope8(dy, cs, sn, (int)(tok % S), rot, l8, true);
             float x[8];
-            Vec8<bf16_t>::load(qkv + vc * HD + 8 * l8, x);
+            Vec8<bf16_t>::load(qkv + (th * 3 + sel) * HD + 8 * l8, x);
             const float mean = stats[(th * 2 + sel) * 2], rstd = stats[(th * 2 + sel) * 2 + 1];
             const float* g = (sel == 0 ? gq : gk) + 8 * l8;
             float s1 = 0.f, s2 = 0.f, gg[8], xh[8];
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const bf16_t* __r
             (void)group8_sum(0.f);
             (void)group8_sum(0.f);
         }
-        if (live) Vec8<bf16_t>::store(dqkv + vc * HD + 8 * l8, dy);
+        if (live) Vec8<bf16_t>::store(dqkv + (th * 3 + sel) * HD + 8 * l8, dy);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -191,12 +197,21 @@ extern "C" {
 
 int otter_qk_norm_rope_fwd(const void* qkv, const float* gamma_q, const float* beta_q, const float* gamma_k, const float* beta_k,
                            const float* cos_t, const float* sin_t, void* q_out, void* k_out, void* v_out, float* stats, int64_t tokens, int64_t S,
-                           int64_t H, int64_t rot, float eps, void* stream) {
-    OTTER_REQUIRE(qkv && gamma_q && beta_q && gamma_k && beta_k && cos_t && sin_t && q_out && k_out && v_out && stats, "qk_norm_rope_fwd: null pointer");
+                           int64_t H, int64_t rot, float eps, int64_t out_width, void* stream) {
+    OTTER_REQUIRE(qkv && gamma_q && beta_q && gamma_k && beta_k && cos_t && sin_t && q_out && k_out && stats, "qk_norm_rope_fwd: null pointer");
     OTTER_REQUIRE(tokens > 0 && S > 0 && H > 0 && rot > 0 && rot <= HD && rot % 16 == 0, "qk_norm_rope_fwd: rot=%ld must be a multiple of 16 in (0, 64]", (long)rot);
-    const int64_t nvec = tokens * H * 3;
-    hipLaunchKernelGGL(qk_norm_rope_fwd_kernel, dim3((unsigned)cdiv64(nvec, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv, gamma_q, beta_q,
-                       gamma_k, beta_k, cos_t, sin_t, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)v_out, stats, nvec, S, (int)H, (int)rot, eps);
+    OTTER_REQUIRE(out_width == HD || out_width == PD, "qk_norm_rope_fwd: out_width %ld (64 = compact heads, 128 = zero-padded)", (long)out_width);
+    const int64_t nvec = tokens * H * (v_out ? 3 : 2);
+    const dim3 grid((unsigned)cdiv64(nvec, 32)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define OTTER_QKN_FWD(NSEL_, PDW_)                                                                                                                  \
+    hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<NSEL_, PDW_>), grid, block, 0, st, (const bf16_t*)qkv, gamma_q, beta_q, gamma_k, beta_k, cos_t, sin_t, \
+                       (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)v_out, stats, nvec, S, (int)H, (int)rot, eps)
+    if (v_out && out_width == PD) OTTER_QKN_FWD(3, PD);
+    else if (v_out) OTTER_QKN_FWD(3, HD);
+    else if (out_width == PD) OTTER_QKN_FWD(2, PD);
+    else OTTER_QKN_FWD(2, HD);
+#undef OTTER_QKN_FWD
     OTTER_CHECK_LAUNCH("qk_norm_rope_fwd");
     return OTTER_OK;
 }
@@ -211,14 +226,23 @@ int64_t otter_qk_norm_rope_bwd_blocks(int64_t tokens, int64_t H) {
 
 int otter_qk_norm_rope_bwd(const void* dq, const void* dk, const void* dv, const void* qkv, const float* stats, const float* gamma_q,
                            const float* gamma_k, const float* cos_t, const float* sin_t, void* dqkv, float* partial, int64_t tokens, int64_t S,
-                           int64_t H, int64_t rot, void* stream) {
-    OTTER_REQUIRE(dq && dk && dv && qkv && stats && gamma_q && gamma_k && cos_t && sin_t && dqkv && partial, "qk_norm_rope_bwd: null pointer");
+                           int64_t H, int64_t rot, int64_t in_width, void* stream) {
+    OTTER_REQUIRE(dq && dk && qkv && stats && gamma_q && gamma_k && cos_t && sin_t && dqkv && partial, "qk_norm_rope_bwd: null pointer");
     OTTER_REQUIRE(tokens > 0 && S > 0 && H > 0 && rot > 0 && rot <= HD && rot % 16 == 0, "qk_norm_rope_bwd: bad rot");
-    const int64_t nvec = tokens * H * 3;
+    OTTER_REQUIRE(in_width == HD || in_width == PD, "qk_norm_rope_bwd: in_width %ld (64 = compact heads, 128 = zero-padded)", (long)in_width);
+    const int64_t nvec = tokens * H * (dv ? 3 : 2);
     const int64_t nb = otter_qk_norm_rope_bwd_blocks(tokens, H);
     const int64_t per = cdiv64(cdiv64(nvec, nb), 32) * 32;
-    hipLaunchKernelGGL(qk_norm_rope_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dq, (const bf16_t*)dk,
-                       (const bf16_t*)dv, (const bf16_t*)qkv, stats, gamma_q, gamma_k, cos_t, sin_t, (bf16_t*)dqkv, partial, nvec, S, (int)H, (int)rot, per);
+    const dim3 grid((unsigned)nb), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define OTTER_QKN_BWD(NSEL_, PDW_)                                                                                                                  \
+    hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<NSEL_, PDW_>), grid, block, 0, st, (const bf16_t*)dq, (const bf16_t*)dk, (const bf16_t*)dv,           \
+                       (const bf16_t*)qkv, stats, gamma_q, gamma_k, cos_t, sin_t, (bf16_t*)dqkv, partial, nvec, S, (int)H, (int)rot, per)
+    if (dv && in_width == PD) OTTER_QKN_BWD(3, PD);
+    else if (dv) OTTER_QKN_BWD(3, HD);
+    else if (in_width == PD) OTTER_QKN_BWD(2, PD);
+    else OTTER_QKN_BWD(2, HD);
+#undef OTTER_QKN_BWD
     OTTER_CHECK_LAUNCH("qk_norm_rope_bwd");
     return OTTER_OK;
 }

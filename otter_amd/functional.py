@@ -836,35 +836,51 @@ def sqrelu(x):
     return SqReLUFn.apply(x)
 
 
+def _persimmon_pad128(H: int) -> bool:
+    """Round 2's layout (heads zero-padded to 128 for the 128-wide flash kernels): odd head counts, or OTTER_FUYU_PAD128=1 (A/B runs)."""
+    return H % 2 == 1 or os.environ.get("OTTER_FUYU_PAD128", "0") == "1"
+
+
 class PersimmonAttentionFn(torch.autograd.Function):
     """Persimmon self-attention core (fuyu/modeling_persimmon.py:262-312) on the per-head interleaved projection output
-    qkv [B,S,H*3*64] (bf16): q/k LayerNorm + partial rotary + head-dim padding in one pass (otter_qk_norm_rope_fwd), causal flash
-    attention on the padded [B,S,H,128] views (csrc/flash.hip; zero columns change neither scores nor outputs), lower 64 output
-    columns gathered into ctx [B,S,H*64].  Backward mirrors it and returns the LayerNorm parameter gradients."""
+    qkv [B,S,H*3*64] (bf16): q/k LayerNorm + partial rotary in one pass (otter_qk_norm_rope_fwd) into compact [B,S,H,64] q / k, causal
+    flash attention on 64-wide heads (csrc/flash.hip, two heads per workgroup) that reads v IN PLACE from qkv and writes ctx directly
+    as [B,S,H*64]; the backward writes dv straight into the v slots of dqkv and the LayerNorm / rotary backward fills the q / k slots.
+    (Round 2 zero-padded q / k / v / dO to 128 columns and gathered ctx from a padded output: `_persimmon_pad128`.)"""
 
     @staticmethod
     def forward(ctx, qkv, gq, bq, gk, bk, cos, sin, H, rot, eps, scale):
         B, S, _ = qkv.shape
         qkv = qkv.contiguous()
         gqf, bqf, gkf, bkf = (t.detach().float().contiguous() for t in (gq, bq, gk, bk))
-        q, k, v, stats = ops.qk_norm_rope_fwd(qkv, gqf, bqf, gkf, bkf, cos, sin, H, rot, eps)
-        o, lse = ops.flash_attn_fwd(q, k, v, None, None, scale, True)            # [B,S,H,128]
+        pad = _persimmon_pad128(H)
+        q, k, v, stats = ops.qk_norm_rope_fwd(qkv, gqf, bqf, gkf, bkf, cos, sin, H, rot, eps, width=128 if pad else 64, copy_v=pad)
+        o, lse = ops.flash_attn_fwd(q, k, v, None, None, scale, True)            # [B,S,H,128 | 64]
         ctx.save_for_backward(qkv, stats, q, k, v, o, lse, gqf, gkf, cos, sin)
-        ctx.cfg = (H, rot, scale, gq.dtype)
+        ctx.cfg = (H, rot, scale, gq.dtype, pad)
         k_c, v_c = k[..., :64], v[..., :64]          # normalised + rotated keys and the values, for a KV cache (not differentiable)
         ctx.mark_non_differentiable(k_c, v_c)
-        return o[..., :64].reshape(B, S, H * 64), k_c, v_c
+        return (o[..., :64].reshape(B, S, H * 64) if pad else o.view(B, S, H * 64)), k_c, v_c
 
     @staticmethod
     def backward(ctx, dctx, _dk, _dv):
         qkv, stats, q, k, v, o, lse, gqf, gkf, cos, sin = ctx.saved_tensors
-        H, rot, scale, pdt = ctx.cfg
+        H, rot, scale, pdt, pad = ctx.cfg
         B, S, _ = qkv.shape
-        do = torch.zeros((B, S, H, 128), dtype=torch.bfloat16, device=qkv.device)
-        do[..., :64] = dctx.reshape(B, S, H, 64)
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        ops.flash_attn_bwd(q, k, v, o, lse, do, dq, dk, dv, None, None, scale, True)
-        dqkv, dgq, dbq, dgk, dbk = ops.qk_norm_rope_bwd(dq, dk, dv, qkv, stats, gqf, gkf, cos, sin, H, rot)
+        if pad:
+            do = torch.zeros((B, S, H, 128), dtype=torch.bfloat16, device=qkv.device)
+            do[..., :64] = dctx.reshape(B, S, H, 64)
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            ops.flash_attn_bwd(q, k, v, o, lse, do, dq, dk, dv, None, None, scale, True)
+            dqkv, dgq, dbq, dgk, dbk = ops.qk_norm_rope_bwd(dq, dk, dv, qkv, stats, gqf, gkf, cos, sin, H, rot)
+        else:
+            do = dctx.reshape(B, S, H, 64)
+            do = do.contiguous() if do.dtype == torch.bfloat16 else do.to(torch.bfloat16).contiguous()
+            dqkv = torch.empty_like(qkv)
+            dq, dk = torch.empty_like(q), torch.empty_like(k)
+            dv = dqkv.view(B, S, H, 3, 64)[:, :, :, 2]
+            ops.flash_attn_bwd(q, k, v, o, lse, do, dq, dk, dv, None, None, scale, True)
+            dqkv, dgq, dbq, dgk, dbk = ops.qk_norm_rope_bwd(dq, dk, None, qkv, stats, gqf, gkf, cos, sin, H, rot, dqkv=dqkv)
         return dqkv, dgq.to(pdt), dbq.to(pdt), dgk.to(pdt), dbk.to(pdt), None, None, None, None, None, None
 
 

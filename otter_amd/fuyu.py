@@ -13,12 +13,12 @@ Same class surface and state-dict keys as the reference / transformers (`languag
 
 bf16 GPU path (every parameter is trainable here, so the GEMMs are torch / hipBLASLt with their wgrad):
   LayerNorm (+ fused residual add)       csrc/norm.hip
-  q / k LayerNorm over head_dim + partial RoPE + head-dim padding   csrc/fuyu.hip: otter_qk_norm_rope_fwd / _bwd, reading the
-                                         per-head interleaved [H,3,d] projection buffer in place
-  causal attention                       csrc/flash.hip (head_dim 128 MFMA kernels): Persimmon's 64-wide heads are zero-padded to
-                                         128 by the kernel above -- exact (zero q/k columns add nothing to the scores, zero v
-                                         columns give zero outputs), at twice the attention FLOPs (~6 % of a layer); a native
-                                         head_dim-64 flash kernel is the known gap
+  q / k LayerNorm over head_dim + partial RoPE   csrc/fuyu.hip: otter_qk_norm_rope_fwd / _bwd, reading the per-head interleaved
+                                         [H,3,d] projection buffer in place, writing compact [B,S,H,64] q / k
+  causal attention                       csrc/flash.hip, head_dim 64 (round 3): two heads per workgroup on the 128-wide tile layouts,
+                                         v read in place from the projection buffer, ctx written as [B,S,H*64], dv written into the
+                                         v slots of dqkv.  (Round 2 zero-padded the heads to 128 columns: twice the attention FLOPs
+                                         and padded q / k / v / dO / o copies; still used for an odd head count, OTTER_FUYU_PAD128=1.)
   squared-ReLU                           csrc/fuyu.hip: otter_sqrelu_fwd / _bwd
   patch embeddings into the sequence     csrc/fuyu.hip: otter_scatter_rows (+ gather for the backward)
 fp32 / CPU: the plain PyTorch expression of the same arithmetic (parity mode; pinned by tests/golden/fuyu_tiny.npz, generated

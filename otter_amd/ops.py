@@ -333,37 +333,39 @@ def attn_bwd(q, k, v, o, do, lse, H, tt, n_per_media, mask_mode, scale, dkv_out=
 # ----------------------------------------------------------------------------------------------------------------------
 
 
-def _flash_view(t: torch.Tensor) -> K.FlashView:
-    """t: a [B, S, H, 128] bf16 view with unit stride along the head dim."""
-    if t.dim() != 4 or t.shape[3] != 128 or t.stride(3) != 1 or t.dtype != torch.bfloat16:
-        raise K.OtterHipError(f"flash attention wants [B,S,H,128] bf16 views (got {tuple(t.shape)}, {t.dtype}, strides {t.stride()})")
+def _flash_view(t: torch.Tensor, hd: int = 128) -> K.FlashView:
+    """t: a [B, S, H, head_dim] bf16 view with unit stride along the head dim."""
+    if t.dim() != 4 or t.shape[3] != hd or t.stride(3) != 1 or t.dtype != torch.bfloat16:
+        raise K.OtterHipError(f"flash attention wants [B,S,H,{hd}] bf16 views (got {tuple(t.shape)}, {t.dtype}, strides {t.stride()})")
     return K.FlashView(t.stride(0), t.stride(1), t.stride(2))
 
 
 def _flash_desc(q, k, v, o, lse, slopes, key_valid, scale, causal) -> K.FlashDesc:
     K.require_cuda(q, k, v, o, lse, slopes, key_valid)
-    B, Sq, H, _ = q.shape
+    B, Sq, H, hd = q.shape
     Sk = k.shape[1]
+    if hd not in (64, 128) or (hd == 64 and H % 2):
+        raise K.OtterHipError(f"flash attention: head_dim 128, or 64 with an even number of heads (got head_dim {hd}, {H} heads)")
     if key_valid is not None and (key_valid.dtype != torch.uint8 or not key_valid.is_contiguous() or key_valid.shape != (B, Sk)):
         raise K.OtterHipError("flash attention: key_valid must be a contiguous uint8 [B, Sk] tensor")
     if slopes is not None and (slopes.dtype != torch.float32 or not slopes.is_contiguous() or slopes.numel() != H):
         raise K.OtterHipError("flash attention: alibi slopes must be a contiguous fp32 [H] tensor")
     d = K.FlashDesc()
     d.q, d.k, d.v, d.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
-    d.qv, d.kv, d.vv, d.ov = _flash_view(q), _flash_view(k), _flash_view(v), _flash_view(o)
+    d.qv, d.kv, d.vv, d.ov = _flash_view(q, hd), _flash_view(k, hd), _flash_view(v, hd), _flash_view(o, hd)
     d.lse = lse.data_ptr()
     d.alibi_slopes = K.ptr(slopes)
     d.key_valid = K.ptr(key_valid)
-    d.B, d.H, d.Sq, d.Sk, d.head_dim, d.causal = B, H, Sq, Sk, 128, int(bool(causal))
+    d.B, d.H, d.Sq, d.Sk, d.head_dim, d.causal = B, H, Sq, Sk, hd, int(bool(causal))
     d.scale = float(scale)
     return d
 
 
 def flash_attn_fwd(q, k, v, slopes, key_valid, scale, causal=True):
-    """Decoder-host attention (mpt/attention.py:22-84 + ALiBi :447-464) on [B,S,H,128] bf16 views.  Returns
-    (o [B,Sq,H,128] contiguous, lse [B,H,Sq] fp32)."""
-    B, Sq, H, _ = q.shape
-    o = torch.empty((B, Sq, H, 128), dtype=torch.bfloat16, device=q.device)
+    """Decoder-host attention (mpt/attention.py:22-84 + ALiBi :447-464) on [B,S,H,128] bf16 views, or Persimmon's
+    (fuyu/modeling_persimmon.py:310) on [B,S,H,64] views with H even.  Returns (o [B,Sq,H,head_dim] contiguous, lse [B,H,Sq] fp32)."""
+    B, Sq, H, hd = q.shape
+    o = torch.empty((B, Sq, H, hd), dtype=torch.bfloat16, device=q.device)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     d = _flash_desc(q, k, v, o, lse, slopes, key_valid, scale, causal)
     K.check(K.lib().otter_flash_attn_fwd(C.byref(d), K.stream()), "flash_attn_fwd")
@@ -371,14 +373,15 @@ def flash_attn_fwd(q, k, v, slopes, key_valid, scale, causal=True):
 
 
 def flash_attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, slopes, key_valid, scale, causal=True):
-    """Writes dq / dk / dv (caller-provided [B,S,H,128] views, e.g. the three slices of one dqkv buffer)."""
+    """Writes dq / dk / dv (caller-provided [B,S,H,head_dim] views, e.g. the three slices of one dqkv buffer)."""
     K.require_cuda(dout, dq, dk, dv)
+    hd = q.shape[3]
     d = _flash_desc(q, k, v, o, lse, slopes, key_valid, scale, causal)
     delta = torch.empty((2,) + tuple(lse.shape), dtype=torch.float32, device=lse.device)  # row dots + log2-domain lse
-    d.dout, d.dov = dout.data_ptr(), _flash_view(dout)
+    d.dout, d.dov = dout.data_ptr(), _flash_view(dout, hd)
     d.delta = delta.data_ptr()
     d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
-    d.dqv, d.dkv, d.dvv = _flash_view(dq), _flash_view(dk), _flash_view(dv)
+    d.dqv, d.dkv, d.dvv = _flash_view(dq, hd), _flash_view(dk, hd), _flash_view(dv, hd)
     K.check(K.lib().otter_flash_attn_bwd(C.byref(d), K.stream()), "flash_attn_bwd")
 
 
@@ -477,38 +480,52 @@ def decode_attn(q, k, v, slopes, key_valid, scale):
     return o
 
 
-def qk_norm_rope_fwd(qkv, gq, bq, gk, bk, cos, sin, H, rot, eps):
-    """qkv [B,S,H*3*64] bf16 (per head q|k|v) -> q', k', v as [B,S,H,128] bf16 (upper 64 columns zero), stats [B*S,H,2,2]."""
+def qk_norm_rope_fwd(qkv, gq, bq, gk, bk, cos, sin, H, rot, eps, width=128, copy_v=True):
+    """qkv [B,S,H*3*64] bf16 (per head q|k|v) -> q', k', v as [B,S,H,width] bf16, stats [B*S,H,2,2].  width 128: upper 64 columns zero
+    (the 128-wide flash kernels); width 64: compact heads (the head-pair kernels), and with copy_v=False v is returned as the strided
+    [B,S,H,64] view of qkv's v slots that those kernels read in place."""
     K.require_cuda(qkv, gq, bq, gk, bk, cos, sin)
     B, S, W = qkv.shape
     if qkv.dtype != torch.bfloat16 or not qkv.is_contiguous() or W != H * 3 * 64:
         raise K.OtterHipError("qk_norm_rope: contiguous bf16 [B,S,H*3*64]")
+    if width not in (64, 128):
+        raise K.OtterHipError("qk_norm_rope: width 64 or 128")
     for t in (gq, bq, gk, bk):
         if t.dtype != torch.float32 or t.numel() != 64 or not t.is_contiguous():
             raise K.OtterHipError("qk_norm_rope: gamma / beta must be contiguous fp32 [64]")
     if cos.dtype != torch.float32 or not cos.is_contiguous() or tuple(cos.shape) != (S, rot) or tuple(sin.shape) != (S, rot) or not sin.is_contiguous():
         raise K.OtterHipError("qk_norm_rope: cos / sin must be contiguous fp32 [S, rot]")
-    q = torch.empty((B, S, H, 128), dtype=torch.bfloat16, device=qkv.device)
-    k, v = torch.empty_like(q), torch.empty_like(q)
+    q = torch.empty((B, S, H, width), dtype=torch.bfloat16, device=qkv.device)
+    k = torch.empty_like(q)
+    v = torch.empty_like(q) if copy_v else None
     stats = torch.empty((B * S, H, 2, 2), dtype=torch.float32, device=qkv.device)
     K.check(K.lib().otter_qk_norm_rope_fwd(qkv.data_ptr(), gq.data_ptr(), bq.data_ptr(), gk.data_ptr(), bk.data_ptr(), cos.data_ptr(), sin.data_ptr(),
-                                           q.data_ptr(), k.data_ptr(), v.data_ptr(), stats.data_ptr(), B * S, S, H, rot, float(eps), K.stream()),
+                                           q.data_ptr(), k.data_ptr(), K.ptr(v), stats.data_ptr(), B * S, S, H, rot, float(eps), width, K.stream()),
             "qk_norm_rope_fwd")
+    if v is None:
+        v = qkv.view(B, S, H, 3, 64)[:, :, :, 2]
     return q, k, v, stats
 
 
-def qk_norm_rope_bwd(dq, dk, dv, qkv, stats, gq, gk, cos, sin, H, rot):
-    """-> (dqkv like qkv, dgamma_q, dbeta_q, dgamma_k, dbeta_k fp32 [64])."""
-    K.require_cuda(dq, dk, dv, qkv, stats)
+def qk_norm_rope_bwd(dq, dk, dv, qkv, stats, gq, gk, cos, sin, H, rot, dqkv=None):
+    """-> (dqkv like qkv, dgamma_q, dbeta_q, dgamma_k, dbeta_k fp32 [64]).  dq / dk (/ dv) contiguous [B,S,H,64] or [B,S,H,128]; dv None:
+    the caller's dqkv already holds the v gradients in its v slots (written in place by the attention backward)."""
+    K.require_cuda(dq, dk, dv, qkv, stats, dqkv)
     B, S, _ = qkv.shape
+    width = dq.shape[-1]
     for t in (dq, dk, dv):
-        if t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (B, S, H, 128):
-            raise K.OtterHipError("qk_norm_rope_bwd: dq / dk / dv must be contiguous bf16 [B,S,H,128]")
-    dqkv = torch.empty_like(qkv)
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_contiguous() or tuple(t.shape) != (B, S, H, width) or width not in (64, 128)):
+            raise K.OtterHipError("qk_norm_rope_bwd: dq / dk / dv must be contiguous bf16 [B,S,H,64] or [B,S,H,128]")
+    if dv is None and dqkv is None:
+        raise K.OtterHipError("qk_norm_rope_bwd: dv=None needs the dqkv buffer whose v slots hold the v gradients")
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    elif dqkv.dtype != torch.bfloat16 or not dqkv.is_contiguous() or dqkv.shape != qkv.shape:
+        raise K.OtterHipError("qk_norm_rope_bwd: dqkv must be contiguous bf16 like qkv")
     nb = int(K.lib().otter_qk_norm_rope_bwd_blocks(B * S, H))
     partial = torch.empty((nb, 4, 64), dtype=torch.float32, device=qkv.device)
-    K.check(K.lib().otter_qk_norm_rope_bwd(dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), qkv.data_ptr(), stats.data_ptr(), gq.data_ptr(), gk.data_ptr(),
-                                           cos.data_ptr(), sin.data_ptr(), dqkv.data_ptr(), partial.data_ptr(), B * S, S, H, rot, K.stream()),
+    K.check(K.lib().otter_qk_norm_rope_bwd(dq.data_ptr(), dk.data_ptr(), K.ptr(dv), qkv.data_ptr(), stats.data_ptr(), gq.data_ptr(), gk.data_ptr(),
+                                           cos.data_ptr(), sin.data_ptr(), dqkv.data_ptr(), partial.data_ptr(), B * S, S, H, rot, width, K.stream()),
             "qk_norm_rope_bwd")
     p = partial.sum(0)
     return dqkv, p[0], p[1], p[2], p[3]

@@ -1,4 +1,4 @@
-"""GPU parity tests of the decoder-host flash attention (otter_flash_attn_fwd / _bwd, head_dim 128) through the C ABI.
+"""GPU parity tests of the decoder-host flash attention (otter_flash_attn_fwd / _bwd, head_dim 128 and 64) through the C ABI.
 
 Inputs are rounded to bf16 first and the oracle (oracle/otter_oracle.py: mpt_attention_core, float64) runs on the rounded
 values.  Tolerances, relative to the tensor's max: outputs 1e-2 (one bf16 rounding of P and of the output), gradients
@@ -98,6 +98,125 @@ def test_flash_attention_fwd_bwd(ops, B, H, S, causal, alibi, lens, variant):
     w = np.where(mask, w, -np.inf)
     ref_lse = np.log(np.exp(w - w.max(-1, keepdims=True)).sum(-1)) + w.max(-1)
     assert np.abs(lse.cpu().double().numpy() - ref_lse).max() < 2e-3
+
+
+CASES64 = [
+    # B, H, S, causal, alibi, right-padded lengths
+    (2, 4, 512, True, False, None),
+    (1, 2, 200, True, True, [150]),
+    (2, 2, 130, False, False, None),
+    (2, 6, 64, True, False, [64, 1]),
+    (1, 4, 321, True, True, [300]),
+    (2, 2, 17, True, False, None),
+    (1, 2, 33, True, True, [33]),
+    (1, 8, 96, True, False, None),
+    (1, 2, 1396, True, False, None),       # C5's sequence length (1296 patch tokens + 36 newlines + 64 text)
+]
+
+
+def _views64(layout, B, S, H, g, fill=None):
+    """q / k / v style [B,S,H,64] bf16 views in one of the layouts the head-pair kernels address in place."""
+    mk = (lambda *sh: (torch.randn(*sh, generator=g) * 0.8).to(torch.bfloat16)) if fill is None else (lambda *sh: torch.full(sh, fill, dtype=torch.bfloat16))
+    if layout == "compact":            # three contiguous [B,S,H,64] tensors (head stride 64)
+        base = [mk(B, S, H, 64).to(DEV) for _ in range(3)]
+        return base, base
+    if layout == "interleaved":        # Persimmon's projection buffer [B,S,H,3,64] (head stride 192)
+        buf = mk(B, S, H, 3, 64).to(DEV)
+        return [buf], [buf[:, :, :, i] for i in range(3)]
+    buf = mk(B, S, 3, H, 64).to(DEV)   # "fused": [B,S,3,H,64] (head stride 64, token stride 3*H*64)
+    return [buf], [buf[:, :, i] for i in range(3)]
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("layout", ["compact", "interleaved", "fused"])
+@pytest.mark.parametrize("B,H,S,causal,alibi,lens", CASES64)
+def test_flash_attention_head_dim_64(ops, B, H, S, causal, alibi, lens, layout, variant):
+    """head_dim 64 (fuyu/modeling_persimmon.py:310; two heads per workgroup) against the float64 oracle, in every layout the kernels address
+    in place, on both block orders."""
+    from otter_amd.mpt import alibi_slopes
+
+    if layout != "interleaved" and variant == 2 and S not in (512, 200, 1396):
+        pytest.skip("A/B variants: one layout per small case is enough")
+    g = torch.Generator().manual_seed(B * 1000 + S + H)
+    _, (q, k, v) = _views64(layout, B, S, H, g)
+    dout = torch.randn(B, S, H, 64, generator=g).to(torch.bfloat16).to(DEV)
+    valid = None
+    if lens is not None:
+        valid = torch.zeros(B, S, dtype=torch.uint8)
+        for b, n in enumerate(lens):
+            valid[b, :n] = 1
+    slopes = alibi_slopes(H, 8).float() if alibi else None
+    scale = 1.0 / math.sqrt(64)
+    sl = slopes.to(DEV) if slopes is not None else None
+    kvd = valid.to(DEV) if valid is not None else None
+    ops.set_flash_variant(variant)
+    try:
+        o, lse = ops.flash_attn_fwd(q, k, v, sl, kvd, scale, causal)
+        _, (dq, dk, dv) = _views64(layout, B, S, H, g, fill=float("nan"))
+        ops.flash_attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, sl, kvd, scale, causal)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_flash_variant(0)
+    assert o.shape == (B, S, H, 64) and o.is_contiguous()
+    f = lambda t: t.float().cpu().double().numpy().transpose(0, 2, 1, 3)
+    qh, kh, vh = f(q), f(k), f(v)
+    ctx, (rdq, rdk, rdv) = O.mpt_attention_core(qh, kh, vh, scale, slopes.numpy() if alibi else None,
+                                                 valid.numpy() if valid is not None else None, causal, f(dout))
+    assert relmax(f(o), ctx) < 1e-2
+    for t in (dq, dk, dv):
+        assert bool(torch.isfinite(t.float()).all())
+    assert relmax(f(dq), rdq) < 2e-2
+    assert relmax(f(dk), rdk) < 2e-2
+    assert relmax(f(dv), rdv) < 2e-2
+    w = (qh @ np.swapaxes(kh, -1, -2)) * scale
+    if alibi:
+        w = w + slopes.numpy().astype(np.float64)[None, :, None, None] * np.arange(1 - S, 1, dtype=np.float64)[None, None, None, :]
+    mask = np.ones((B, 1, S, S), bool)
+    if valid is not None:
+        mask = mask & valid.numpy().astype(bool)[:, None, None, :]
+    if causal:
+        mask = mask & np.tril(np.ones((S, S), bool))[None, None]
+    w = np.where(mask, w, -np.inf)
+    ref_lse = np.log(np.exp(w - w.max(-1, keepdims=True)).sum(-1)) + w.max(-1)
+    assert np.abs(lse.cpu().double().numpy() - ref_lse).max() < 2e-3
+
+
+def test_flash_head_pairs_equal_zero_padded_heads(ops):
+    """The head-pair kernels against round 2's route (heads zero-padded to 128 columns on the 128-wide kernels) at C5's attention shape
+    (B=4 here 2, 64 heads, 1396 tokens): zero columns add exact zeros to every product, so outputs and gradients agree to rounding of the
+    differently grouped sums -- and the pair kernels must leave the neighbouring q / k slots of the interleaved buffers untouched."""
+    B, H, S = 2, 64, 1396
+    g = torch.Generator().manual_seed(11)
+    buf = (torch.randn(B, S, H, 3, 64, generator=g) * 0.8).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B, S, H, 64, generator=g).to(torch.bfloat16).to(DEV)
+    scale = 1.0 / math.sqrt(64)
+    q, k, v = (buf[:, :, :, i] for i in range(3))
+    o, lse = ops.flash_attn_fwd(q, k, v, None, None, scale, True)
+    dbuf = torch.full_like(buf, 7.0)
+    dq, dk = torch.empty_like(o), torch.empty_like(o)
+    ops.flash_attn_bwd(q, k, v, o, lse, dout, dq, dk, dbuf[:, :, :, 2], None, None, scale, True)
+    assert bool((dbuf[:, :, :, :2] == 7.0).all())           # only the v slots were written
+    pad = lambda t: torch.cat([t, torch.zeros_like(t)], -1).contiguous()
+    qp, kp, vp, dop = pad(q), pad(k), pad(v), pad(dout)
+    op, lsep = ops.flash_attn_fwd(qp, kp, vp, None, None, scale, True)
+    dqp, dkp, dvp = torch.empty_like(qp), torch.empty_like(qp), torch.empty_like(qp)
+    ops.flash_attn_bwd(qp, kp, vp, op, lsep, dop, dqp, dkp, dvp, None, None, scale, True)
+    torch.cuda.synchronize()
+    assert float((lse - lsep).abs().max()) < 1e-5
+    for a, b in ((o, op), (dq, dqp), (dk, dkp), (dbuf[:, :, :, 2], dvp)):
+        a, b = a.float(), b[..., :64].float()
+        assert float((a - b).abs().max()) <= 8e-3 * float(b.abs().max())
+
+
+def test_flash_head_dim_64_rejects_what_it_cannot_address(ops):
+    from otter_amd._capi import OtterHipError
+
+    q = torch.zeros(1, 64, 3, 64, dtype=torch.bfloat16, device=DEV)          # odd head count
+    with pytest.raises(OtterHipError, match="even"):
+        ops.flash_attn_fwd(q, q, q, None, None, 0.125, True)
+    t = torch.zeros(1, 64, 2, 64, dtype=torch.bfloat16, device=DEV).transpose(1, 2).contiguous().transpose(1, 2)   # [B,S,H,64] with head stride S*64
+    with pytest.raises(OtterHipError, match="head_stride"):
+        ops.flash_attn_fwd(t, t, t, None, None, 0.125, True)
 
 
 def test_flash_batch_rows_independent(ops):

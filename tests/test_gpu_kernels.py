@@ -892,6 +892,19 @@ def test_qk_norm_rope_fwd_bwd(ops, rot):
     assert relmax(host(dqkv).reshape(B, S, H, 3, d), tq.grad.numpy()) < 1.5e-2
     for got, want in ((dgq, tg[0]), (dbq, tg[1]), (dgk, tg[2]), (dbk, tg[3])):
         assert relmax(host(got), want.grad.numpy()) < 1e-3
+    # round 3's layout for the head-pair attention kernels: compact 64-wide q / k, v left in place (a strided view of qkv), and a backward
+    # that fills only the q / k slots of a dqkv whose v slots the attention backward has written
+    qkv_d = to_dev(qkv.reshape(B, S, H * 3 * d), torch.bfloat16)
+    q2, k2, v2, stats2 = ops.qk_norm_rope_fwd(qkv_d, dev(gq), dev(bq), dev(gk), dev(bk), dev(cos), dev(sin), H, rot, eps, width=64, copy_v=False)
+    assert q2.shape == (B, S, H, 64) and q2.is_contiguous() and v2.data_ptr() == qkv_d.data_ptr() + 2 * 128 and v2.stride() == (S * H * 192, H * 192, 192, 1)
+    assert torch.equal(q2, q[..., :64]) and torch.equal(k2, k[..., :64]) and torch.equal(v2, v[..., :64]) and torch.equal(stats2, stats)
+    dqkv2 = torch.full_like(qkv_d, float("nan"))
+    dqkv2.view(B, S, H, 3, d)[:, :, :, 2] = to_dev(dv, torch.bfloat16)
+    out2, dgq2, dbq2, dgk2, dbk2 = ops.qk_norm_rope_bwd(to_dev(dq, torch.bfloat16), to_dev(dk, torch.bfloat16), None, qkv_d, stats2, dev(gq), dev(gk), dev(cos),
+                                                        dev(sin), H, rot, dqkv=dqkv2)
+    assert out2.data_ptr() == dqkv2.data_ptr() and torch.equal(dqkv2, dqkv)
+    for a_, b_ in ((dgq2, dgq), (dbq2, dbq), (dgk2, dgk), (dbk2, dbk)):     # same terms, another blocking of the fp32 partial sums
+        assert relmax(host(a_), host(b_)) < 1e-5
 
 
 def test_sqrelu_and_scatter_rows(ops):
