@@ -157,7 +157,7 @@ def run_c5(args, device, rank, world, use_dist):
             "value": round(B * world * args.steps / elapsed, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") +
+            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") + ("DEBUG-ONE-GPU-GLOO " if os.environ.get("OTTER_BENCH_DEBUG_ONE_GPU") == "1" else "") +
                        "OtterHD / Fuyu-8B full fine-tune step (BASELINE configs[4]): %d pairs per GPU, sequence %d = 36x(36 patches + newline) + %d text, "
                        "every parameter trainable (%.2f B), bf16 autocast, fp32 masters" % (B, S, text_len, n_par / 1e9),
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
@@ -352,14 +352,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DEBUG ONLY (not a valid bench): every rank on cuda:0, collectives over gloo -- runs the whole N > 1 code path (spawn, reducer hooks,
+    # embedding-row all-gather, max-over-ranks timing) on a one-GPU box, where RCCL refuses two ranks on one device
+    one_gpu = os.environ.get("OTTER_BENCH_DEBUG_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_dist = world > 1 or os.environ.get("OTTER_FORCE_DIST") == "1"  # the env switch exercises the RCCL path on one GPU
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if args.config == "c5":
         # 8 pairs per GPU = the reference's OtterHD recipe (docs/OtterHD.md:66, shared_scripts/Demo_OtterHD.sh: --batch_size=8); the fixed
@@ -450,7 +457,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") +
+            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") + ("DEBUG-ONE-GPU-GLOO " if os.environ.get("OTTER_BENCH_DEBUG_ONE_GPU") == "1" else "") +
                                    (("OTTER-Image-MPT7B instruction-following train step, 1x224^2 image + %d tokens per pair, "
                                      "batch %d per GPU (BASELINE configs[1]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B)) if args.config == "c2" else
                                     ("OTTER-Video-LLaMA7B-DenseCaption train step, 8x224^2 frames (T_img=1, F=8: 2048 patches) + %d tokens per pair, "
