@@ -136,12 +136,19 @@ class PersimmonDecoderLayer(nn.Module):
         self.input_layernorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.post_attention_layernorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
 
-    def forward(self, x, cos, sin, attn_mask=None, past_key_value=None, use_cache=False, hip=False):
+    def forward(self, x, cos, sin, attn_mask=None, past_key_value=None, use_cache=False, hip=False, pending=None, defer=False):
+        """hip path: `pending` is the previous layer's MLP output, not yet added to the residual stream -- the add rides in this layer's
+        first LayerNorm pass; with `defer` the layer hands its own MLP output back the same way ((x, past, mlp_out) instead of (x, past))."""
         if hip:
             n1, n2 = self.input_layernorm, self.post_attention_layernorm
-            a = OF.layer_norm(x, n1.weight, n1.bias, n1.eps, torch.bfloat16)
+            if pending is not None:
+                x, a = OF.add_layer_norm(x, pending, n1.weight, n1.bias, n1.eps, torch.bfloat16)   # x = x + pending ; a = LN(x)  (one pass)
+            else:
+                a = OF.layer_norm(x, n1.weight, n1.bias, n1.eps, torch.bfloat16)
             b, new_past = self.self_attn(a, cos, sin, use_cache=use_cache, hip=True)
             x, m = OF.add_layer_norm(x, b, n2.weight, n2.bias, n2.eps, torch.bfloat16)   # x = x + b ; m = LN(x)  (one pass)
+            if defer:
+                return x, new_past, self.mlp(m)
             return x + self.mlp(m), new_past
         b, new_past = self.self_attn(self.input_layernorm(x), cos, sin, attn_mask=attn_mask, past_key_value=past_key_value, use_cache=use_cache)
         x = x + b
@@ -233,13 +240,20 @@ class PersimmonModel(PersimmonPreTrainedModel):
                 mask = mask.expand(B, -1, -1, -1).masked_fill(~am[:, None, None, -s_k:], neg)
             mask = mask.to(OF.compute_dtype_for(x))
         new_pasts = [] if use_cache else None
+        pending = None      # hip path: a layer's MLP output joins the residual stream inside the NEXT LayerNorm pass (one kernel less per layer)
         for i, layer in enumerate(self.layers):
             pkv = past_key_values[i] if (past_key_values is not None and len(past_key_values) > i) else None
-            x, npkv = layer(x, cos, sin, attn_mask=mask, past_key_value=pkv, use_cache=use_cache, hip=hip)
+            if hip:
+                x, npkv, pending = layer(x, cos, sin, use_cache=use_cache, hip=True, pending=pending, defer=True)
+            else:
+                x, npkv = layer(x, cos, sin, attn_mask=mask, past_key_value=pkv, use_cache=use_cache)
             if use_cache:
                 new_pasts.append(npkv)
         n = self.final_layernorm
-        x = OF.layer_norm(x, n.weight, n.bias, n.eps, OF.compute_dtype_for(x)) if x.is_cuda else n(x)
+        if pending is not None:
+            x = OF.add_layer_norm(x, pending, n.weight, n.bias, n.eps, OF.compute_dtype_for(x))[1]
+        else:
+            x = OF.layer_norm(x, n.weight, n.bias, n.eps, OF.compute_dtype_for(x)) if x.is_cuda else n(x)
         return BaseModelOutputWithPast(last_hidden_state=x, past_key_values=tuple(new_pasts) if use_cache else None)
 
 
