@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/gpurun_out; cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_$NAME
 timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$NAME -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /tmp/prof_$NAME.log 2>&1
-tail -1 /tmp/prof_$NAME.log > $ROOT/gpurun_out/${NAME}_bench.json
+grep '^{"metric' /tmp/prof_$NAME.log | tail -1 > $ROOT/gpurun_out/${NAME}_bench.json   # (the last line of the log is rocprofv3's own)
 f=$(find /tmp/prof_$NAME -name "*kernel_stats.csv" | head -1)
 python - "$f" "$ROOT/gpurun_out/${NAME}_kernel_stats.txt" "$ROOT/gpurun_out/${NAME}_bench.json" <<'PY'
 import csv, sys
