@@ -218,8 +218,10 @@ int otter_qk_norm_rope_fwd(const void* qkv, const float* gamma_q, const float* b
 
 int64_t otter_qk_norm_rope_bwd_blocks(int64_t tokens, int64_t H) {
     const int64_t nvec = tokens * H * 3;
-    int64_t nb = cdiv64(nvec, 32 * 64);          // >= 64 iterations of 32 vectors per block
-    if (nb > 2048) nb = 2048;
+    // 16 iterations of 32 vectors per block, at most 4096 blocks (C5 shape: 256 -> 180 us per launch against 64 iterations / 2048 blocks, which
+    // left the 256 CUs with under three blocks each; 8 / 8192 and 4 / 16384 are slower again: the partial sums grow)
+    int64_t nb = cdiv64(nvec, 32 * 16);
+    if (nb > 4096) nb = 4096;
     if (nb < 1) nb = 1;
     return nb;
 }
