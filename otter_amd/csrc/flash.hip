@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
                     }
             };
             head(std::integral_constant<int, 0>{});
-            __builtin_amdgcn_sched_barrier(0);   // heads apart: interleaved, both heads' score registers are live at once
+            __builtin_amdgcn_sched_barrier(0);   // heads apart: interleaved, both heads' score registers are live at once (56 B of scratch)
             head(std::integral_constant<int, 1>{});
             continue;
         }
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
                         dq[2 * e + dbl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Kc, to1, to2, 2 * e + dbl, 32 * kbk + 16 * c), dsf,
                                                                                   dq[2 * e + dbl], 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one (key block, head) at a time: interleaved, the kernel outgrows its 256 registers
+                __builtin_amdgcn_sched_barrier(0);   // one (key block, head) at a time (without it: same time, 450 vs 451 us per backward)
             };
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
