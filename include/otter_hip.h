@@ -112,7 +112,8 @@ int otter_rmsnorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
  *   OTTER_EPI_SCALE_RES C = acc * s + R                  (x = attn(...) * attn_gate.tanh() + x, :380-393;
  *                                                          gate == NULL gives the perceiver's plain residual :180,184)
  *   OTTER_EPI_GATE_BWD  C = s * acc * f'(aux);  partial[block] = sum(acc * f(aux))
- *                       f = identity (aux_is_gelu_input == 0) or gelu_erf (aux_is_gelu_input != 0).
+ *                       f = identity (aux_is_gelu_input == 0), gelu_erf (1) or the squared ReLU relu(a)^2 of the Persimmon MLP
+ *                       (2; /root/reference/src/otter_ai/models/fuyu/modeling_persimmon.py:180-194).
  *                       This is the dgrad GEMM of a gated branch: it yields d(branch input) and, through the
  *                       deterministic two-stage reduction otter_reduce_partials, the gradient of the scalar gate.
  * A/B are both ab_dtype.  bf16 operands run on MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate); f32 operands
@@ -132,7 +133,7 @@ typedef struct {
     const void* aux;     /* GATE_BWD */
     int64_t ldaux;
     int aux_dtype;
-    int aux_is_gelu_input;
+    int aux_is_gelu_input; /* 0 identity, 1 erf GELU, 2 squared ReLU */
     float* partial;      /* GATE_BWD: [otter_gemm_num_partials(M,N)] floats, or NULL */
 } otter_epilogue_args;
 

@@ -125,7 +125,14 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
         default: {  // OTTER_EPI_GATE_BWD
             float a[4];
             load4(g.aux, m * g.ldaux + n, g.auxdt, a);
-            if (g.aux_gelu) {   // tested outside the element loop (a per-element scalar branch serialises the chains)
+            if (g.aux_gelu == 2) {   // squared ReLU (Persimmon MLP): f(a) = relu(a)^2, f'(a) = 2 relu(a)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float r = fmaxf(a[i], 0.f);
+                    part += v[i] * (r * r);
+                    o[i] = s * v[i] * (2.0f * r);
+                }
+            } else if (g.aux_gelu) {   // tested outside the element loop (a per-element scalar branch serialises the chains)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     // gelu and gelu' share the erf: one transcendental chain instead of two
@@ -209,7 +216,14 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m
         default: {  // OTTER_EPI_GATE_BWD
             float a[8];
             load8w(g.aux, m * g.ldaux + n, g.auxdt, a);
-            if (g.aux_gelu) {
+            if (g.aux_gelu == 2) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float r = fmaxf(a[i], 0.f);
+                    part += v[i] * (r * r);
+                    o[i] = s * v[i] * (2.0f * r);
+                }
+            } else if (g.aux_gelu) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float cdf, pdf;
@@ -390,7 +404,14 @@ __device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t 
     } else {
         // the aux kind is tested ONCE, outside the element loop: inside it the compiler kept a scalar branch between
         // elements, which serialised eight independent rcp / exp / fma chains (gate-backward tail: 88 k cycles per tile)
-        if (g.aux_gelu) {
+        if (g.aux_gelu == 2) {   // squared ReLU: f'(a) = 2 relu(a)
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float r = fmaxf(a[i], 0.f);
+                part += v[i] * (r * r);
+                o[i] = s * v[i] * (2.0f * r);
+            }
+        } else if (g.aux_gelu) {
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 float cdf, pdf;
@@ -4033,6 +4054,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
             break;
         case OTTER_EPI_GATE_BWD:
             OTTER_REQUIRE(g.aux && g.ldaux % 4 == 0, "gemm: GATE_BWD needs aux with ldaux %% 4 == 0");
+            OTTER_REQUIRE(g.aux_gelu >= 0 && g.aux_gelu <= 2, "gemm: aux activation %d (0 = identity, 1 = erf GELU, 2 = squared ReLU)", g.aux_gelu);
             break;
         default:
             OTTER_FAIL(OTTER_ERR_ARG, "gemm: unknown epilogue %d", g.kind);

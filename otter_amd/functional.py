@@ -946,8 +946,9 @@ def _kmajor_wgrad_any_size(dy2, x2):
     return dW
 
 
-def _kmajor_dgrad_any_size(dy2, Wb):
-    """dx = dy W (W stored [out, in] = the K-major B operand), dy cut into row blocks when it spans 4 GB or more.  None when unsupported."""
+def _kmajor_dgrad_any_size(dy2, Wb, sqrelu_of=None):
+    """dx = dy W (W stored [out, in] = the K-major B operand), dy cut into row blocks when it spans 4 GB or more.  None when unsupported.
+    With `sqrelu_of` = h [rows, n_in] the GEMM's tail multiplies by 2 relu(h): the input gradient of W . relu(h)^2 in one launch."""
     rows, n_out = dy2.shape
     n_in = Wb.shape[1]
     if Wb.stride(0) * 2 * n_out >= _SPAN_LIMIT:
@@ -958,15 +959,18 @@ def _kmajor_dgrad_any_size(dy2, Wb):
     step = -(-step // 256) * 256
     if not ops.gemm_kmajor_supported(min(step, rows), n_in, n_out, dy2.stride(0), Wb.stride(0), False, True, dy2.dtype):
         return None
+    epi = (lambda r0, r1: {}) if sqrelu_of is None else (lambda r0, r1: dict(kind=EPI_GATE_BWD, aux=sqrelu_of[r0:r1], aux_gelu="sqrelu"))
     if parts == 1:
-        return ops.gemm(dy2, Wb, False, True)
+        return ops.gemm(dy2, Wb, False, True, **epi(0, rows))
     dx = torch.empty((rows, n_in), dtype=dy2.dtype, device=dy2.device)
     for r0 in range(0, rows, step):
         r1 = min(r0 + step, rows)
         if not ops.gemm_kmajor_supported(r1 - r0, n_in, n_out, dy2.stride(0), Wb.stride(0), False, True, dy2.dtype):
             torch.mm(dy2[r0:r1], Wb, out=dx[r0:r1])      # a short last block (< 192 tiles)
+            if sqrelu_of is not None:
+                dx[r0:r1] = ops.sqrelu_bwd(sqrelu_of[r0:r1].contiguous(), dx[r0:r1].contiguous())
         else:
-            ops.gemm(dy2[r0:r1], Wb, False, True, out=dx[r0:r1])
+            ops.gemm(dy2[r0:r1], Wb, False, True, out=dx[r0:r1], **epi(r0, r1))
     return dx
 
 
@@ -1017,6 +1021,67 @@ class TrainableLinearFn(torch.autograd.Function):
             db = ops.colsum(dy2, None, dy2.shape[0])
             db = db if db.dtype == ctx.bdtype else db.to(ctx.bdtype)
         return dx, dW, db
+
+
+class SqReLULinearFn(torch.autograd.Function):
+    """y = relu(h)^2 W^T + b, the second half of the Persimmon MLP (fuyu/modeling_persimmon.py:180-194: fused_mlp_func "sqrelu") for a
+    TRAINABLE Linear: like TrainableLinearFn, and the activation's backward rides in the tail of the input-gradient GEMM
+    (dh = (dy W) . 2 relu(h) in one launch of the K-major kernel: no separate pass over three [tokens, 4 hidden] tensors)."""
+
+    @staticmethod
+    def forward(ctx, h, W, b):
+        shp = h.shape
+        h2 = h.reshape(-1, shp[-1])
+        h2 = (h2 if h2.dtype == torch.bfloat16 else h2.to(torch.bfloat16)).contiguous()
+        a2 = ops.sqrelu_fwd(h2)
+        Wb = shadows.w(W, torch.bfloat16)
+        ctx.save_for_backward(h2, a2, W)
+        ctx.has_bias = b is not None
+        ctx.shp = shp
+        ctx.bdtype = b.dtype if b is not None else None
+        return F.linear(a2, Wb, b.detach().to(torch.bfloat16) if b is not None else None).view(shp[:-1] + (W.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        h2, a2, W = ctx.saved_tensors
+        N = W.shape[0]
+        dy2 = dy.reshape(-1, N)
+        dy2 = (dy2 if dy2.dtype == torch.bfloat16 else dy2.to(torch.bfloat16)).contiguous()
+        dh = None
+        if ctx.needs_input_grad[0]:
+            Wb = shadows.w(W, torch.bfloat16)
+            if os.environ.get("OTTER_NO_KMAJOR") != "1" and os.environ.get("OTTER_NO_KMAJOR_DGRAD") != "1" and os.environ.get("OTTER_NO_SQRELU_TAIL") != "1":
+                dh = _kmajor_dgrad_any_size(dy2, Wb, sqrelu_of=h2)
+            if dh is None:
+                da = None
+                if os.environ.get("OTTER_NO_KMAJOR") != "1" and os.environ.get("OTTER_NO_KMAJOR_DGRAD") != "1":
+                    da = _kmajor_dgrad_any_size(dy2, Wb)
+                dh = ops.sqrelu_bwd(h2, da if da is not None else torch.mm(dy2, Wb))
+            dh = dh.view(ctx.shp)
+        dW = None
+        if ctx.needs_input_grad[1]:
+            dW = _kmajor_wgrad_any_size(dy2, a2) if os.environ.get("OTTER_NO_KMAJOR") != "1" else None
+            if dW is None:
+                try:
+                    dW = torch.mm(dy2.t(), a2, out_dtype=torch.float32)
+                except TypeError:  # older torch: no out_dtype
+                    dW = torch.mm(dy2.t(), a2).float()
+            dW = dW if dW.dtype == W.dtype else dW.to(W.dtype)
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy2, None, dy2.shape[0])
+            db = db if db.dtype == ctx.bdtype else db.to(ctx.bdtype)
+        return dh, dW, db
+
+
+def sqrelu_linear(mod, h):
+    """mod(relu(h)^2) for the Persimmon MLP's second Linear; the fused autograd path under the conditions of `trainable_linear`."""
+    W = mod.weight
+    if (h.is_cuda and h.dtype == torch.bfloat16 and h.shape[-1] % 8 == 0 and W.requires_grad and W.dtype == torch.float32
+            and compute_dtype_for(h) == torch.bfloat16 and torch.is_grad_enabled() and W.shape[0] % 8 == 0 and os.environ.get("OTTER_TORCH_LINEAR") != "1"):
+        return SqReLULinearFn.apply(h, W, mod.bias)
+    a = sqrelu(h) if (h.is_cuda and h.dtype == torch.bfloat16 and h.shape[-1] % 8 == 0) else torch.square(F.relu(h))
+    return trainable_linear(mod, a)
 
 
 def trainable_linear(mod, x):

@@ -60,12 +60,8 @@ class PersimmonMLP(nn.Module):
         self.dense_4h_to_h = nn.Linear(config.intermediate_size, config.hidden_size)
 
     def forward(self, x):
-        h = OF.trainable_linear(self.dense_h_to_4h, x)
-        if h.is_cuda and h.dtype == torch.bfloat16 and h.shape[-1] % 8 == 0:
-            h = OF.sqrelu(h)
-        else:
-            h = torch.square(F.relu(h))
-        return OF.trainable_linear(self.dense_4h_to_h, h)
+        # relu(h)^2 and the second Linear in one autograd node: the activation's backward rides in the input-gradient GEMM's tail
+        return OF.sqrelu_linear(self.dense_4h_to_h, OF.trainable_linear(self.dense_h_to_4h, x))
 
 
 class PersimmonAttention(nn.Module):

@@ -213,7 +213,7 @@ def gemm_nt(A, B, out_dtype=None, out=None, kind=EPI_STORE, gate=None, R=None, C
     if aux is not None:
         aux = _c2d(aux)
         e.aux, e.ldaux, e.aux_dtype = aux.data_ptr(), aux.stride(0), K.dt(aux)
-    e.aux_is_gelu_input = 1 if aux_gelu else 0
+    e.aux_is_gelu_input = 2 if aux_gelu == "sqrelu" else (1 if aux_gelu else 0)    # activation whose derivative the GATE_BWD tail applies to aux
     e.partial = K.ptr(partial)
     if _GEMM_LOG is not None:
         _GEMM_LOG[(M, N, Kd, kind, str(A.dtype).split(".")[-1], str(out.dtype).split(".")[-1])] += 1

@@ -309,13 +309,16 @@ def test_gemm_epilogues(ops, dt, variant):
         assert relmax(host(C), acc * s) < tol
         ops.gemm_nt(dA, dB, out=C, kind=EPI_STORE, accumulate=True)
         assert relmax(host(C), acc * s + acc) < tol
-        # GATE_BWD, both aux kinds
-        for aux_gelu in (False, True):
+        # GATE_BWD, the three aux activations (identity, erf GELU, squared ReLU)
+        for aux_gelu in (False, True, "sqrelu"):
             part = torch.zeros(ops.gemm_num_partials(M, N, tdt), dtype=torch.float32, device=DEV)
             C = ops.gemm_nt(dA, dB, out_dtype=torch.float32, kind=EPI_GATE_BWD, gate=dgate, aux=to_dev(aux, tdt), aux_gelu=aux_gelu,
                             partial=part)
-            f = O.gelu_fwd(aux.astype(np.float64)) if aux_gelu else aux
-            fp = O.gelu_grad(aux.astype(np.float64)) if aux_gelu else 1.0
+            if aux_gelu == "sqrelu":
+                f, fp = np.maximum(aux, 0.0) ** 2, 2.0 * np.maximum(aux, 0.0)
+            else:
+                f = O.gelu_fwd(aux.astype(np.float64)) if aux_gelu else aux
+                fp = O.gelu_grad(aux.astype(np.float64)) if aux_gelu else 1.0
             assert relmax(host(C), s * acc * fp) < tol
             dg = ops.reduce_partials(part, gate=dgate)
             assert abs(float(dg[0]) - (acc * f).sum() * (1 - s * s)) < 1e-3 * abs((acc * f).sum() * (1 - s * s)) + 1e-3
@@ -535,6 +538,11 @@ def test_gemm_kmajor_operands(ops, M, N, Kd, ta, tb, pad):
         x1 = ops.gemm(dA, dB, ta, tb, kind=EPI_GATE_BWD, gate=gate, aux=aux, aux_gelu=True, partial=p1)
         x2 = ops.gemm_nt(to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16), kind=EPI_GATE_BWD, gate=gate, aux=aux, aux_gelu=True, partial=p2)
         assert torch.equal(x1, x2) and torch.equal(p1, p2)
+        # the Persimmon MLP's launch: dh = (dy W) . 2 relu(h), no gate, no partial sums; against the unfused pair (GEMM, then otter_sqrelu_bwd)
+        x3 = ops.gemm(dA, dB, ta, tb, kind=EPI_GATE_BWD, aux=aux, aux_gelu="sqrelu")
+        plain = ops.gemm(dA, dB, ta, tb, out_dtype=torch.float32)
+        want3 = plain * 2.0 * torch.relu(aux.float())
+        assert relmax(host(x3), host(want3)) < 1e-2 and relmax(host(x3), host(ops.sqrelu_bwd(aux, plain.to(torch.bfloat16)))) < 2e-2
 
 
 def test_gemm_kmajor_any_reduction_length(ops):
