@@ -396,7 +396,17 @@ def main():
         # the reference builds the labels inside its step (instruction_following.py:163-192): same here, on the device, no host sync
         return step(vision_x, ids, amask, masking(ids, *tok_ids))
 
+    # DIAGNOSTIC (not a valid bench): OTTER_BENCH_OCCUPY_CUS=n parks n workgroups that each pin a whole CU (all of its LDS) on a side stream
+    # for the timed region -- what the GEMMs see while a collective's kernel is resident
+    n_occ = int(os.environ.get("OTTER_BENCH_OCCUPY_CUS", "0"))
+    if os.environ.get("OTTER_BENCH_FORCE_NONPERSISTENT") == "1":   # A/B leg without an occupier: the per-tile grids on a free chip
+        ops.set_gemm_persistent(False)
+    occ_flag = torch.zeros(1, dtype=torch.int32, device=device) if n_occ else None
+
     def sync():
+        if n_occ:
+            torch.cuda.current_stream().synchronize()      # (a device-wide wait would wait for the occupier itself)
+            return
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -405,6 +415,13 @@ def main():
     loss = None
     for _ in range(args.warmup):
         loss = one_step()
+    if n_occ:
+        from otter_amd import _capi as _K
+        if os.environ.get("OTTER_BENCH_NONPERSISTENT") == "1":     # the grids TrainStep selects while a DP reducer is attached
+            ops.set_gemm_persistent(False)
+        side = torch.cuda.Stream()
+        torch.cuda.current_stream().synchronize()
+        _K.check(_K.lib().otter_debug_occupy_cus(n_occ, occ_flag.data_ptr(), 60 * 100_000_000, side.cuda_stream), "occupy_cus")
     M, N, Kd = B * T, 16384, 4096
     ops.prof_arm_gemm(M, N, Kd, max_events=max(64, args.steps * 8 * 3 + 8))
     sync()
@@ -413,6 +430,9 @@ def main():
         loss = one_step()
     sync()
     elapsed = time.perf_counter() - t0
+    if n_occ:
+        occ_flag.fill_(1)
+        torch.cuda.synchronize()
     n_launch, gemm_ms, n_km, km_ms = ops.prof_collect_split()
     ops.prof_disarm()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -444,7 +464,7 @@ def main():
             if n_km and n_launch > n_km:
                 roof["by_layout"] = {"k_contiguous": {"launches": n_launch - n_km, "avg_us": round((gemm_ms - km_ms) / (n_launch - n_km) * 1e3, 1)},
                                      "k_major": {"launches": n_km, "avg_us": round(km_ms / n_km * 1e3, 1)}}
-            if world == 1 and os.environ.get("OTTER_FORCE_DIST") != "1":   # (no DP reducer hooks on the parameters: stand-alone backward is safe)
+            if world == 1 and os.environ.get("OTTER_FORCE_DIST") != "1" and not n_occ:   # (no DP reducer hooks on the parameters: stand-alone backward is safe)
                 roof["gated_block"] = gated_block_roofline(model, batch, B, T, device)
         out = {
             "metric": ("image-text pairs/s (train step) OTTER-MPT7B, 1 img+512 tok" if args.config == "c2"
@@ -460,7 +480,7 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
-            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") + ("DEBUG-ONE-GPU-GLOO " if os.environ.get("OTTER_BENCH_DEBUG_ONE_GPU") == "1" else "") +
+            "config": {"workload": ("DEBUG-REDUCED (%d layers) " % args.debug_layers if args.debug_layers else "") + ("DEBUG-ONE-GPU-GLOO " if os.environ.get("OTTER_BENCH_DEBUG_ONE_GPU") == "1" else "") + ("DIAGNOSTIC-%d-CUS-OCCUPIED " % n_occ if n_occ else "") +
                                    (("OTTER-Image-MPT7B instruction-following train step, 1x224^2 image + %d tokens per pair, "
                                      "batch %d per GPU (BASELINE configs[1]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B)) if args.config == "c2" else
                                     ("OTTER-Video-LLaMA7B-DenseCaption train step, 8x224^2 frames (T_img=1, F=8: 2048 patches) + %d tokens per pair, "

@@ -401,6 +401,9 @@ int otter_prof_disarm(void);
 int otter_prof_collect(int* count, double* total_ms);
 /* same, with the launches that had a K-major operand (otter_gemm) counted separately as well (they are included in count / total_ms) */
 int otter_prof_collect_split(int* count, double* total_ms, int* count_kmajor, double* kmajor_ms);
+/* Diagnostics (bench.py OTTER_BENCH_OCCUPY_CUS): n workgroups that each pin one CU's whole LDS and sleep until *flag
+ * (device memory) becomes non-zero or max_ticks of the 100 MHz wall clock pass -- stands in for a communication kernel's hold on CUs. */
+int otter_debug_occupy_cus(int n_workgroups, int* flag, unsigned long long max_ticks, void* stream);
 
 #ifdef __cplusplus
 }

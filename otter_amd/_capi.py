@@ -63,6 +63,7 @@ SIGNATURES = {
     "otter_abi_version": (_int, []),
     "otter_last_error": (C.c_char_p, []),
     "otter_device_check": (_int, []),
+    "otter_debug_occupy_cus": (_int, [_int, _vp, C.c_ulonglong, _vp]),
     "otter_layernorm_fwd": (_int, [_vp, _int, _vp, _vp, _int, _vp, _int, RowMap, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "otter_add_layernorm_fwd": (_int, [_vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _i64, _i64, _f32, _vp]),
     "otter_layernorm_bwd_workspace_bytes": (_i64, [_i64, _i64]),

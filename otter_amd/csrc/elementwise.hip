@@ -283,6 +283,14 @@ __global__ void add_rows_kernel(T* __restrict__ dst, const T* __restrict__ src, 
     Vec8<T>::store(dst + row * D + col, a);
 }
 
+
+__global__ __launch_bounds__(256) void occupy_kernel(int* flag, unsigned long long max_ticks) {
+    extern __shared__ char occupy_lds[];
+    if (threadIdx.x == 0) occupy_lds[0] = 1;
+    const unsigned long long t0 = wall_clock64();
+    while (__atomic_load_n(flag, __ATOMIC_RELAXED) == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(127);
+}
+
 }  // namespace
 
 extern "C" {
@@ -438,6 +446,23 @@ int otter_add_frame_embs(void* x, int x_dtype, const float* emb, int64_t outer, 
     else
         hipLaunchKernelGGL((add_frame_embs_kernel<float>), grid, block, 0, (hipStream_t)stream, (float*)x, emb, F, inner, D, nchunks);
     OTTER_CHECK_LAUNCH("add_frame_embs");
+    return OTTER_OK;
+}
+
+
+// Diagnostics (bench.py OTTER_BENCH_OCCUPY_CUS): n workgroups that each hold a whole CU's LDS and sleep until *flag != 0 (or max_ticks of the
+// 100 MHz wall clock) -- what a communication kernel does to the GEMMs' view of the chip: no workgroup that needs LDS can share those CUs.
+int otter_debug_occupy_cus(int n_workgroups, int* flag, unsigned long long max_ticks, void* stream) {
+    OTTER_REQUIRE(n_workgroups > 0 && n_workgroups <= 256 && flag, "occupy_cus: 1..256 workgroups and a device flag");
+    static bool once = false;
+    const int lds = 160 * 1024;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) OTTER_FAIL(OTTER_ERR_LAUNCH, "occupy_cus: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        once = true;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3((unsigned)n_workgroups), dim3(256), lds, (hipStream_t)stream, flag, max_ticks);
+    OTTER_CHECK_LAUNCH("occupy_cus");
     return OTTER_OK;
 }
 
