@@ -3,8 +3,10 @@
 The reference forwards its kwargs to the third-party `GenerationMixin.generate` of the pinned transformers==4.35.1 (not
 importable with the transformers installed here).  What its own call sites use is restated here:
 greedy search, beam search (`num_beams=3, no_repeat_ngram_size=3, bad_words_ids=...`: pipeline/demos/interactive/*.py,
-pipeline/benchmarks/models/otter_{image,video}.py; `length_penalty`, `min_new_tokens`: the benchmark wrappers) and
-temperature / top-k / top-p sampling (pipeline/demos/demo_models.py:64-71,120-130).  The algorithm is transformers'
+pipeline/benchmarks/models/otter_{image,video}.py; `length_penalty`, `min_new_tokens`: the benchmark wrappers),
+temperature / top-k / top-p sampling (pipeline/demos/demo_models.py:64-71,120-130; the serve UI's `do_sample` checkbox,
+pipeline/serve/gradio_web_server.py:362-371) and -- no call site of the reference combines them, restated so that the two switches compose
+as they do in GenerationMixin -- beam-sample (`num_beams > 1` with `do_sample`).  The algorithm is transformers'
 (generation/utils.py beam_search + generation/beam_search.py BeamSearchScorer + generation/logits_process.py), restated on
 plain tensors around a `step` callback so that it serves both decoder hosts and both decode modes (KV cache or full
 re-forward).  Pinned by tests/test_generation.py against `transformers`' own generate() on a shared tiny LLaMA.
@@ -152,8 +154,6 @@ def generate_tokens(step: StepFn, input_ids: torch.Tensor, attention_mask: Optio
             raise NotImplementedError("otter_amd.generate: unsupported generation arguments %s" % bad)
     if num_return_sequences != 1 and not (num_beams > 1 and num_return_sequences <= num_beams):
         raise NotImplementedError("num_return_sequences > 1 needs num_beams >= num_return_sequences (beam search)")
-    if do_sample and num_beams > 1:
-        raise NotImplementedError("beam-sample (do_sample with num_beams > 1) is not implemented")
     B, L0 = input_ids.shape
     dev = input_ids.device
     eos = [] if eos_token_id is None else ([int(eos_token_id)] if isinstance(eos_token_id, int) else [int(e) for e in eos_token_id])
@@ -208,8 +208,22 @@ def generate_tokens(step: StepFn, input_ids: torch.Tensor, attention_mask: Optio
         logp = torch.log_softmax(logits.float(), dim=-1)
         logp = proc(ids, logp)
         V = logp.shape[-1]
-        scores = (logp + beam_scores[:, None]).view(B, nb * V)
-        ns, ni = torch.topk(scores, max(2, 1 + len(eos)) * nb, dim=1, largest=True, sorted=True)
+        n_cand = max(2, 1 + len(eos)) * nb
+        if do_sample:
+            # beam-sample (generation/utils.py beam_sample): the warpers act on the processed log-probabilities of each beam (at least as many
+            # tokens kept as candidates are drawn per beam pair), candidates are DRAWN from softmax(score + beam score) over all beams of a
+            # sentence instead of taken by top-k, then ranked by that score
+            if temperature is not None and temperature != 1.0:
+                logp = logp / float(temperature)
+            logp = _top_k_top_p(logp, int(top_k or 0), float(top_p if top_p is not None else 1.0), min_keep=max(2, 1 + len(eos)))
+            scores = (logp + beam_scores[:, None]).view(B, nb * V)
+            ni = torch.multinomial(scores.softmax(-1), n_cand, generator=generator)
+            ns = scores.gather(1, ni)
+            ns, order = torch.sort(ns, descending=True, dim=1)
+            ni = ni.gather(1, order)
+        else:
+            scores = (logp + beam_scores[:, None]).view(B, nb * V)
+            ns, ni = torch.topk(scores, n_cand, dim=1, largest=True, sorted=True)
         n_idx, n_tok = (ni // V).tolist(), (ni % V).tolist()
         ns_l = ns.tolist()
         cur_len = ids.shape[1] + 1

@@ -102,8 +102,44 @@ def test_unsupported_arguments_are_loud(pair):
     ids = torch.ones(1, 3, dtype=torch.long)
     with pytest.raises(NotImplementedError):
         generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beam_groups=2, diversity_penalty=0.5)
-    with pytest.raises(NotImplementedError):
-        generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beams=2, do_sample=True)
+
+
+def test_beam_sample_properties(pair):
+    """Beam-sample (num_beams > 1 with do_sample; transformers 4.35.1 generation/utils.py beam_sample: candidates DRAWN from
+    softmax(warped log-probabilities + beam scores), then ranked).  The installed transformers draws the same candidates but ranks the finished
+    ones by their position in the draw, so its final pick can differ from the pinned version's; what is pinned here: the run is a function of
+    the generator, every emitted token lies in its beam's top-k support given its prefix, the n-gram rule holds, and with one beam the loop
+    degenerates to plain sampling."""
+    from otter_amd.generation import generate_tokens
+
+    cfg, ref, mine = pair
+    ids = torch.randint(3, cfg.vocab_size, (3, 6), generator=torch.Generator().manual_seed(17))
+    mask = torch.ones_like(ids)
+    kw = dict(eos_token_id=1, pad_token_id=0, num_beams=3, do_sample=True, temperature=0.9, top_k=4, max_new_tokens=9, no_repeat_ngram_size=2)
+    a = generate_tokens(_step_for(mine, True), ids, mask, generator=torch.Generator().manual_seed(3), **kw)
+    b = generate_tokens(_step_for(mine, False), ids, mask, generator=torch.Generator().manual_seed(3), **kw)
+    c = generate_tokens(_step_for(mine, True), ids, mask, generator=torch.Generator().manual_seed(4), **kw)
+    assert torch.equal(a, b) and a.shape[0] == 3 and a.shape[1] <= 6 + 9
+    assert not torch.equal(a, c)                       # another seed, another draw (3 sentences x 9 steps: a collision is not credible)
+    with torch.no_grad():
+        logits = mine(input_ids=a, attention_mask=torch.ones_like(a)).logits
+    for r in range(a.shape[0]):
+        seq = a[r].tolist()
+        grams = set()
+        for t in range(6, len(seq)):
+            if seq[t] == 0 and 1 in seq[6:t]:          # padding after eos
+                break
+            lp = torch.log_softmax(logits[r, t - 1].float(), -1)
+            bigrams = {(seq[i], seq[i + 1]) for i in range(t - 1)}
+            banned = [v for v in range(cfg.vocab_size) if (seq[t - 1], v) in bigrams]
+            lp[banned] = float("-inf")
+            assert seq[t] in lp.topk(4).indices.tolist(), (r, t, seq)
+            assert (seq[t - 1], seq[t]) not in grams
+            grams.add((seq[t - 1], seq[t]))
+    # several sequences per sentence come back best first, as from beam search
+    d = generate_tokens(_step_for(mine, True), ids, mask, generator=torch.Generator().manual_seed(3), num_return_sequences=2,
+                        **{k: v for k, v in kw.items()})
+    assert d.shape[0] == 6 and torch.equal(d[0::2][:, :a.shape[1]], a[:, :d.shape[1]])
 
 
 @pytest.mark.parametrize("kw", [dict(num_beams=1, max_new_tokens=10), dict(num_beams=3, max_new_tokens=10, no_repeat_ngram_size=3)])
