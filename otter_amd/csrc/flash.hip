@@ -352,7 +352,7 @@ __device__ __forceinline__ void flash_dma_tile(u32x4_t rk, u32x4_t rv, char* kds
 // score).  Separate interior / masked paths as in the 128-wide kernels did not fit the 256 registers of two workgroups per CU (84-392 B of
 // scratch per lane, reloaded through VMEM in front of every tile) and measured slower, as did one workgroup per CU with 512 registers
 // (C5 shape, forward / backward: 142 / 451 us one path, 153 / 650 two paths, 196 / 505 one workgroup per CU; zero-padded heads 205 / 694).
-template <bool LPT, bool PAIR = false>
+template <bool LPT, bool PAIR = false, bool ALIBI = true>   // ALIBI = false (pair kernels only): no slopes, the bias arithmetic is compiled out
 __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
-                        float x = fmaf(sp[kbk][r], sc2, fmaf(sle, (float)cidx, base));
+                        float x = ALIBI ? fmaf(sp[kbk][r], sc2, fmaf(sle, (float)cidx, base)) : sp[kbk][r] * sc2;
                         {   // v_bfe_i32 + v_bfi_b32: 0 / ~0 from the key's bit, then x or -inf
                             const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)(cidx < 32 ? okm_lo : okm_hi), cidx & 31, 1);
                             x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, x) & mk) | (~mk & 0xFF800000u));
@@ -925,7 +925,7 @@ __device__ __forceinline__ bf16x8_t tr_pi_frag(const char* tile, int o1, int o2,
     return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <bool LPT, bool PAIR = false>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
+template <bool LPT, bool PAIR = false, bool ALIBI = true>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
             vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
         }
         if constexpr (PAIR) {
-            // bit cidx: the lane's key cidx of the tile is visible (one code path for interior and masked tiles: see the forward)
+            // bit cidx: the lane's key cidx of the tile is visible (see the forward)
             const unsigned long long okm = limh < 0 ? 0ull : (limh >= 63 ? vmh : vmh & ((2ull << limh) - 1ull));
             const unsigned okm_lo = (unsigned)okm, okm_hi = (unsigned)(okm >> 32);
             auto part = [&](auto KBK, auto E) {
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
-                    float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, fmaf(sle, (float)cidx, be)));
+                    float p = __builtin_amdgcn_exp2f(ALIBI ? fmaf(s[r], sc2, fmaf(sle, (float)cidx, be)) : fmaf(s[r], sc2, be));
                     const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)(cidx < 32 ? okm_lo : okm_hi), cidx & 31, 1);
                     p = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) & mk);
                     s[r] = p * (dp[r] - dle);
@@ -1611,13 +1611,21 @@ int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
         const int smem = 65536 + KMASK_TILES * 8;
         static bool once = false;
         if (!once) {
-            rc = set_smem(flash_fwd2_kernel<false, true>, smem); if (rc) return rc;
-            rc = set_smem(flash_fwd2_kernel<true, true>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<false, true, true>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<true, true, true>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<false, true, false>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<true, true, false>, smem); if (rc) return rc;
             once = true;
         }
         const unsigned nqb = (unsigned)((a.Sq + 127) / 128), hb = (unsigned)(a.H / 2);
-        if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, true>), dim3(nqb * hb * a.B), dim3(256), smem, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((flash_fwd2_kernel<false, true>), dim3(nqb, hb, a.B), dim3(256), smem, (hipStream_t)stream, a);
+        const dim3 g1(nqb * hb * a.B), g3(nqb, hb, a.B);
+        if (a.slopes) {
+            if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, true, true>), g1, dim3(256), smem, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((flash_fwd2_kernel<false, true, true>), g3, dim3(256), smem, (hipStream_t)stream, a);
+        } else {
+            if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, true, false>), g1, dim3(256), smem, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((flash_fwd2_kernel<false, true, false>), g3, dim3(256), smem, (hipStream_t)stream, a);
+        }
     } else if (v2) {
 #ifdef OTTER_FLASH_TIMING
         const int smem = 65536 + KMASK_TILES * 8 + 1024;
@@ -1626,13 +1634,13 @@ int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
 #endif
         static bool once = false;
         if (!once) {
-            rc = set_smem(flash_fwd2_kernel<false, false>, smem); if (rc) return rc;
-            rc = set_smem(flash_fwd2_kernel<true, false>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<false, false, true>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd2_kernel<true, false, true>, smem); if (rc) return rc;
             once = true;
         }
         const unsigned nqb = (unsigned)((a.Sq + 127) / 128);
-        if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, false>), dim3(nqb * a.H * a.B), dim3(256), smem, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((flash_fwd2_kernel<false, false>), dim3(nqb, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, false, true>), dim3(nqb * a.H * a.B), dim3(256), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((flash_fwd2_kernel<false, false, true>), dim3(nqb, a.H, a.B), dim3(256), smem, (hipStream_t)stream, a);
     } else {
         const int smem = 64 * LDK * 2 + 64 * LDT * 2;
         static bool once = false;
@@ -1662,16 +1670,23 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
         if (!once) {
             rc = set_smem(flash_bwd_dkv2_kernel<1, false, true>, smem_kv); if (rc) return rc;
             rc = set_smem(flash_bwd_dkv2_kernel<1, true, true>, smem_kv); if (rc) return rc;
-            rc = set_smem(flash_bwd_dq2_kernel<false, true>, smem_q); if (rc) return rc;
-            rc = set_smem(flash_bwd_dq2_kernel<true, true>, smem_q); if (rc) return rc;
+            rc = set_smem(flash_bwd_dq2_kernel<false, true, true>, smem_q); if (rc) return rc;
+            rc = set_smem(flash_bwd_dq2_kernel<true, true, true>, smem_q); if (rc) return rc;
+            rc = set_smem(flash_bwd_dq2_kernel<false, true, false>, smem_q); if (rc) return rc;
+            rc = set_smem(flash_bwd_dq2_kernel<true, true, false>, smem_q); if (rc) return rc;
             once = true;
         }
         const unsigned nkb = (unsigned)((a.Sk + 127) / 128), nqb = (unsigned)((a.Sq + 127) / 128), hb = (unsigned)(a.H / 2);
         if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, true>), dim3(nkb * hb * a.B), dim3(256), smem_kv, st, a);
         else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, true>), dim3(nkb, hb, a.B), dim3(256), smem_kv, st, a);
         OTTER_CHECK_LAUNCH("flash_bwd_dkv");
-        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
-        else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
+        if (a.slopes) {
+            if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true, true>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
+            else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true, true>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
+        } else {
+            if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true, false>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
+            else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true, false>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
+        }
         OTTER_CHECK_LAUNCH("flash_bwd_dq");
         return OTTER_OK;
     }
@@ -1687,8 +1702,8 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
             rc = set_smem(flash_bwd_dkv2_kernel<2, false, false>, smem_kv); if (rc) return rc;
             rc = set_smem(flash_bwd_dkv2_kernel<1, true, false>, smem_kv); if (rc) return rc;
             rc = set_smem(flash_bwd_dkv2_kernel<2, true, false>, smem_kv); if (rc) return rc;
-            rc = set_smem((flash_bwd_dq2_kernel<false, false>), smem_q); if (rc) return rc;
-            rc = set_smem((flash_bwd_dq2_kernel<true, false>), smem_q); if (rc) return rc;
+            rc = set_smem((flash_bwd_dq2_kernel<false, false, true>), smem_q); if (rc) return rc;
+            rc = set_smem((flash_bwd_dq2_kernel<true, false, true>), smem_q); if (rc) return rc;
             once = true;
         }
         const unsigned nkb = (unsigned)((a.Sk + 127) / 128);
@@ -1698,8 +1713,8 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
         else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
         OTTER_CHECK_LAUNCH("flash_bwd_dkv");
         const unsigned nqb = (unsigned)((a.Sq + 127) / 128);
-        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, false>), dim3(nqb * a.H * a.B), dim3(256), smem_q, st, a);
-        else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, false>), dim3(nqb, a.H, a.B), dim3(256), smem_q, st, a);
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, false, true>), dim3(nqb * a.H * a.B), dim3(256), smem_q, st, a);
+        else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, false, true>), dim3(nqb, a.H, a.B), dim3(256), smem_q, st, a);
         OTTER_CHECK_LAUNCH("flash_bwd_dq");
         return OTTER_OK;
     }
