@@ -371,6 +371,10 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if os.environ.get("OTTER_BENCH_FORCE_NONPERSISTENT") == "1":   # A/B switch: one workgroup per tile instead of the persistent grids
+        from otter_amd import ops as _ops
+
+        _ops.set_gemm_persistent(False)
     if args.config == "c5":
         # 8 pairs per GPU = the reference's OtterHD recipe (docs/OtterHD.md:66, shared_scripts/Demo_OtterHD.sh: --batch_size=8); the fixed
         # cost of the step (clip + AdamW over 9.41 B parameters, 54 ms) is then spread over twice the pairs of round 2's first runs (B=4)
