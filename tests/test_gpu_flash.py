@@ -111,6 +111,8 @@ CASES64 = [
     (1, 2, 33, True, True, [33]),
     (1, 8, 96, True, False, None),
     (1, 2, 1396, True, False, None),       # C5's sequence length (1296 patch tokens + 36 newlines + 64 text)
+    (1, 2, 1, True, False, None),          # a single token
+    (2, 4, 5, False, True, [5, 2]),        # less than one fragment row, non-causal, padded
 ]
 
 
