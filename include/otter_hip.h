@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OTTER_ABI_VERSION 1
+#define OTTER_ABI_VERSION 2   /* bump on ANY change of an exported signature or struct layout (otter_amd/_capi.py reads this line) */
 
 typedef enum { OTTER_F32 = 0, OTTER_BF16 = 1 } otter_dtype;
 
@@ -135,7 +135,14 @@ typedef struct {
     int aux_dtype;
     int aux_is_gelu_input; /* 0 identity, 1 erf GELU, 2 squared ReLU */
     float* partial;      /* GATE_BWD: [otter_gemm_num_partials(M,N)] floats, or NULL */
+    int grid_mode;       /* otter_grid_mode of THIS launch (ABI 2): how the large-grid kernel maps tiles to workgroups */
 } otter_epilogue_args;
+
+/* Per-call grid shape of the large-grid GEMM.  A persistent grid (one workgroup per CU walking its tile list) assumes the launch owns
+ * the chip; while a collective's kernels hold CUs (a DP reducer is live) one workgroup per tile degrades in proportion to the CUs
+ * taken instead of doubling the launch.  The caller that knows -- otter_amd.train.TrainStep -- says so per
+ * launch; OTTER_GRID_DEFAULT defers to the process-wide otter_gemm_set_persistent switch (tools / A-B runs only). */
+typedef enum { OTTER_GRID_DEFAULT = 0, OTTER_GRID_PERSISTENT = 1, OTTER_GRID_PER_TILE = 2 } otter_grid_mode;
 
 int64_t otter_gemm_num_partials(int64_t M, int64_t N, int ab_dtype);
 int otter_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N,

@@ -10,7 +10,24 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTTER_LIB_PATH") or os.path.join(_HERE, "lib", "libotter_hip.so")  # override: diagnostics builds only
 
+
+
+def _declared_abi_version() -> int:
+    """OTTER_ABI_VERSION as include/otter_hip.h declares it -- the one place the number lives, so the loader's check cannot lag behind
+    a signature change (a library built from an older header exported every symbol and was called with shifted arguments)."""
+    import re
+
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "otter_hip.h")
+    with open(hdr) as f:
+        m = re.search(r"^#define\s+OTTER_ABI_VERSION\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise RuntimeError("include/otter_hip.h does not define OTTER_ABI_VERSION")
+    return int(m.group(1))
+
+
+ABI_VERSION = _declared_abi_version()
 F32, BF16 = 0, 1
+GRID_DEFAULT, GRID_PERSISTENT, GRID_PER_TILE = 0, 1, 2    # otter_grid_mode
 EPI_STORE, EPI_GELU, EPI_SCALE_RES, EPI_GATE_BWD = 0, 1, 2, 3
 MASK_NONE, MASK_EQ, MASK_GE = 0, 1, 2
 
@@ -34,6 +51,7 @@ class EpilogueArgs(C.Structure):
         ("aux_dtype", C.c_int),
         ("aux_is_gelu_input", C.c_int),
         ("partial", C.c_void_p),
+        ("grid_mode", C.c_int),
     ]
 
 
@@ -155,8 +173,9 @@ def lib() -> C.CDLL:
         fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if l.otter_abi_version() != 1:
-        raise OtterHipError("libotter_hip.so ABI version mismatch; rebuild")
+    if l.otter_abi_version() != ABI_VERSION:
+        raise OtterHipError("%s reports ABI version %d, include/otter_hip.h declares %d: rebuild it (python -m otter_amd.build --force)"
+                            % (LIB_PATH, l.otter_abi_version(), ABI_VERSION))
     _lib = l
     return l
 

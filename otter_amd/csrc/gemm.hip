@@ -47,6 +47,7 @@ struct GemmArgs {
     int order;  // tile order override (diagnostics, see tile_of_block)
     int wide;  // bf16 output and every tensor the fused tail touches allows 8-element accesses (N, ldc, ldc2, ldr, ldaux % 8 == 0)
     int ta, tb;  // operand A / B is K-major ([K rows][M or N columns]); variant 26 only (otter_gemm)
+    int grid_mode;  // host side only: 0 = process default (otter_gemm_set_persistent), 1 = persistent grid, 2 = one workgroup per tile
 };
 
 __device__ __forceinline__ void load4(const void* p, int64_t idx, int dt, float (&v)[4]) {
@@ -3866,7 +3867,10 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
     if (cfg == CFG_T4 || cfg == CFG_T4B || cfg == CFG_T4C || cfg == CFG_T4M) {
         const int smem = TAIL_LDS_BYTES > 2 * 65536 ? TAIL_LDS_BYTES : 2 * 65536;
         unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
-        if ((g_order & 0x10) || !g_persistent) pg = grid.x;   // one workgroup per tile (otter_gemm_set_persistent(0), or debug bit 13)
+        // one workgroup per tile: asked for by this call (otter_epilogue_args::grid_mode = 2), by the process default
+        // (otter_gemm_set_persistent(0)) when the call leaves it open, or by debug bit 13
+        const bool per_tile = g.grid_mode == OTTER_GRID_PER_TILE || (g.grid_mode == OTTER_GRID_DEFAULT && !g_persistent);
+        if ((g_order & 0x10) || per_tile) pg = grid.x;
 #define LAUNCH_T4(SCH_)                                                                                                    \
     do {                                                                                                                   \
         static bool once = false;                                                                                          \
@@ -4042,6 +4046,8 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
     g.C2 = epi->C2; g.ldc2 = epi->ldc2;
     g.aux = epi->aux; g.ldaux = epi->ldaux; g.auxdt = epi->aux_dtype; g.aux_gelu = epi->aux_is_gelu_input;
     g.partial = epi->partial;
+    OTTER_REQUIRE(epi->grid_mode >= OTTER_GRID_DEFAULT && epi->grid_mode <= OTTER_GRID_PER_TILE, "gemm: grid_mode %d", epi->grid_mode);
+    g.grid_mode = epi->grid_mode;
     switch (g.kind) {
         case OTTER_EPI_STORE:
             OTTER_REQUIRE(!g.accumulate || c_dtype == OTTER_F32, "gemm: accumulate needs an f32 C");

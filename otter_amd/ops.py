@@ -215,6 +215,7 @@ def gemm_nt(A, B, out_dtype=None, out=None, kind=EPI_STORE, gate=None, R=None, C
         e.aux, e.ldaux, e.aux_dtype = aux.data_ptr(), aux.stride(0), K.dt(aux)
     e.aux_is_gelu_input = 2 if aux_gelu == "sqrelu" else (1 if aux_gelu else 0)    # activation whose derivative the GATE_BWD tail applies to aux
     e.partial = K.ptr(partial)
+    e.grid_mode = _grid_mode
     if _GEMM_LOG is not None:
         _GEMM_LOG[(M, N, Kd, kind, str(A.dtype).split(".")[-1], str(out.dtype).split(".")[-1])] += 1
     if a_kmajor or b_kmajor:
@@ -598,6 +599,33 @@ def gemm_variant_available(v: int) -> bool:
     """True when schedule `v` is compiled into the loaded library (the product build carries 0-3, 13, 25, 26; the rest live in the
     tools-only experimental build: OTTER_LIB_PATH=otter_amd/lib/libotter_hip_experimental.so)."""
     return bool(K.lib().otter_gemm_variant_available(int(v)))
+
+
+# Grid shape of the large-grid GEMM launches issued while a `gemm_grid_mode(...)` scope is open (otter_grid_mode in include/otter_hip.h).
+# The scope is a module variable, not a thread-local: the backward products are launched from autograd's device thread, not from the thread
+# that called TrainStep.__call__.  It is set for the duration of ONE training step by the TrainStep that owns a DP reducer and restored
+# when the step returns, so another model (an inference model, a second TrainStep without a reducer) in the same process launches with
+# its own mode -- nothing is left behind in the library (VERDICT r3 weak 12).
+_grid_mode = K.GRID_DEFAULT
+
+
+class gemm_grid_mode:
+    """with ops.gemm_grid_mode(K.GRID_PER_TILE): ...  -- every otter_gemm / otter_gemm_nt launch inside asks for that grid shape."""
+
+    def __init__(self, mode: int):
+        if mode not in (K.GRID_DEFAULT, K.GRID_PERSISTENT, K.GRID_PER_TILE):
+            raise ValueError("gemm_grid_mode: %r" % (mode,))
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        global _grid_mode
+        self.prev, _grid_mode = _grid_mode, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _grid_mode
+        _grid_mode = self.prev
+        return False
 
 
 def set_gemm_persistent(on: bool) -> None:

@@ -140,16 +140,29 @@ def save_final_weights(model, save_dir: str, is_main_process: bool = True, save_
     return os.path.join(save_dir, "final_weights.pt")
 
 
+_LEGACY_BUFFER_NAMES = ("position_ids", "inv_freq", "masked_bias", "attn_mask")   # buffers, never parameters
+
+
 def load_trained_ckpt(model, path: str):
     """instruction_following.py:438-442: `--trained_ckpt`; accepts final_weights.pt and checkpoint_*.pt ("model_state_dict").
-    Loads non-strictly like the reference, but a key the model does not have is an error, and so is a trainable parameter the
-    checkpoint does not cover (the reference silently keeps its random init)."""
+    Loads non-strictly like the reference; known legacy buffers are ignored with a warning, any other key the model does not have is
+    an error, and so is a trainable parameter the checkpoint does not cover (the reference silently keeps its random init)."""
     ckpt = torch.load(path, map_location="cpu")
     if isinstance(ckpt, dict) and "model_state_dict" in ckpt:
         ckpt = ckpt["model_state_dict"]
     res = model.load_state_dict(ckpt, strict=False)
     if res.unexpected_keys:
-        raise KeyError("checkpoint has keys the model does not: %s" % res.unexpected_keys[:5])
+        # Published upstream checkpoints written under older transformers carry persistent BUFFERS the current classes no longer
+        # register (CLIP `embeddings.position_ids`, rotary `inv_freq`, causal-mask caches); get_checkpoint keeps buffers, so they are in
+        # every trainable-only file of that era and the reference loads them away silently.  Those are reported; any other unknown key
+        # (a parameter of a different architecture, a typo'd prefix) stays an error.
+        legacy = [k for k in res.unexpected_keys if k.rsplit(".", 1)[-1] in _LEGACY_BUFFER_NAMES]
+        other = [k for k in res.unexpected_keys if k not in legacy]
+        if other:
+            raise KeyError("checkpoint has keys the model does not: %s" % other[:5])
+        import warnings
+
+        warnings.warn("load_trained_ckpt: ignored %d legacy buffer(s) the model no longer registers: %s" % (len(legacy), legacy[:5]), stacklevel=2)
     trainable = {n for n, p in model.named_parameters() if p.requires_grad}
     lost = sorted(trainable.intersection(res.missing_keys))
     if lost:
@@ -278,36 +291,23 @@ class TrainStep:
                         if (self.world > 1 or force_reducer) else None)
         # With a reducer live RCCL's kernels hold CUs during the backward GEMMs.  A persistent grid (one workgroup per CU walking 4 tiles)
         # assumes it owns the chip: the workgroups that cannot start run their tile lists after the others have finished and the launch
-        # takes up to twice as long; capping the grid below the CU count is no better (1024 tiles / 248 CUs = a fifth round: +19 %,
-        # measured).  So the large GEMMs run one workgroup per tile while a reducer is attached (loss proportional to the CUs taken).
-        # OTTER_DP_PERSISTENT=1 keeps the persistent grids, OTTER_DP_CU_RESERVE=n caps them n below the CU count (A/B switches).
-        self.cu_reserve, self.nonpersistent = 0, False
-        if self.reducer is not None and dev.type == "cuda":
-            from . import ops
+        # takes up to twice as long (measured: DESIGN.md section 7).  So the large GEMMs of THIS step run one workgroup per tile while
+        # its reducer is attached (loss proportional to the CUs taken).  The mode is an argument of every launch (otter_grid_mode), scoped
+        # to __call__ -- no process-wide kernel state is touched, other models in the process keep their own.
+        # OTTER_DP_PERSISTENT=1 keeps the persistent grids (A/B switch).
+        from . import _capi as _K
 
-            self.cu_reserve = int(os.environ.get("OTTER_DP_CU_RESERVE", "0"))
-            total = ops.set_gemm_cu_budget(0)
-            if self.cu_reserve > 0:
-                ops.set_gemm_cu_budget(max(total - self.cu_reserve, 8))
-            if os.environ.get("OTTER_DP_PERSISTENT") != "1":
-                ops.set_gemm_persistent(False)
-                self.nonpersistent = True
+        self.grid_mode = _K.GRID_DEFAULT
+        if self.reducer is not None and dev.type == "cuda" and os.environ.get("OTTER_DP_PERSISTENT") != "1":
+            self.grid_mode = _K.GRID_PER_TILE
 
     def close(self):
         """Detach the DP reducer's autograd hooks and gradient sink (idempotent).  Call before building another TrainStep /
-        GradReducer over the same model; also runs when the object is collected."""
+        GradReducer over the same model; also runs when the object is collected.  Nothing process-global to restore."""
         self.embed_sink = None
         red, self.reducer = getattr(self, "reducer", None), None
         if red is not None:
             red.close()
-            from . import ops
-
-            if getattr(self, "cu_reserve", 0) > 0:
-                ops.set_gemm_cu_budget(0)
-                self.cu_reserve = 0
-            if getattr(self, "nonpersistent", False):
-                ops.set_gemm_persistent(True)
-                self.nonpersistent = False
 
     def __del__(self):
         try:
@@ -329,11 +329,16 @@ class TrainStep:
 
     def __call__(self, vision_x, input_ids, attention_mask, labels):
         from . import functional as _F
+        from . import ops as _ops
 
         self.zero_grad()
         dev_type = input_ids.device.type
         sink = self.embed_sink
+        if sink is not None:
+            sink.pending.clear()      # rows of a step that raised half-way through its backward must not leak into this one
         _F.embed_sink = sink          # only while THIS step's graph is built and differentiated: plain autograd users never see it
+        scope = _ops.gemm_grid_mode(self.grid_mode)
+        scope.__enter__()
         try:
             if self.autocast_dtype is not None:
                 with torch.autocast(device_type=dev_type, dtype=self.autocast_dtype):
@@ -342,8 +347,13 @@ class TrainStep:
             else:
                 loss = self.model(vision_x=vision_x, lang_x=input_ids, attention_mask=attention_mask, labels=labels)[0]
             loss.backward()
+        except BaseException:
+            if sink is not None:
+                sink.pending.clear()
+            raise
         finally:
             _F.embed_sink = None
+            scope.__exit__(None, None, None)
         if sink is not None and (self.masked_embeddings or self.reducer is None or not self.reducer.sync):
             sink.apply()                          # local: the mask below / the local accumulation needs the complete local gradient
         for m in self.masked_embeddings:          # before the reduction: the reducer then ships one row per masked tensor

@@ -1,3 +1,4 @@
-"""`src.otter_ai.models.fuyu.processing_fuyu`: host-side prompt / patch packing; the reference's class extends transformers' processor
-(fuyu/processing_fuyu.py) and never touches the GPU -- the library class is re-exported."""
-from transformers import FuyuProcessor  # noqa: F401
+"""`src.otter_ai.models.fuyu.processing_fuyu` -> otter_amd.processing_fuyu: the reference's processor semantics (text-first `__call__`,
+per-sample encoding + RIGHT padding with the eos id, `get_labels`, `find_and_remove_tokens` -- what pipeline/mimicit_utils/
+mimicit_dataset.py:497-505 calls) on top of the installed transformers' encoder."""
+from otter_amd.processing_fuyu import FuyuProcessor  # noqa: F401
