@@ -50,7 +50,7 @@ CLIP_L14 = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, 
                 patch_size=14, hidden_act="quick_gelu", layer_norm_eps=1e-5, projection_dim=768)
 
 
-def build_model(device, seed=0, debug_layers=0, config="c2"):
+def build_model(device, seed=0, debug_layers=0, config="c2", frozen_dtype=torch.bfloat16):
     from otter_amd.configuration_otter import OtterConfig
     from otter_amd.modeling_otter import OtterForConditionalGeneration
 
@@ -72,9 +72,10 @@ def build_model(device, seed=0, debug_layers=0, config="c2"):
                 p.fill_(0.5)  # zero-init gates make the block an identity (modeling_otter.py:362,371)
         # frozen weights live in bf16 (288 GB HBM would hold fp32 too, but bf16 halves the weight stream of the frozen
         # GEMMs); trainable parameters keep fp32 masters, exactly like accelerate's bf16 mixed precision.
+        # (frozen_dtype=torch.float32: the fp32 parity mode of tests/test_gpu_full_model.py -- same architecture, same initial values)
         for name, p in model.named_parameters():
             if not p.requires_grad:
-                p.data = p.data.to(torch.bfloat16)
+                p.data = p.data.to(frozen_dtype)
     model.train()
     return model
 
@@ -111,16 +112,24 @@ def run_c5(args, device, rank, world, use_dist):
     grid, P = 36, 36 * 36
     S = grid * (grid + 1) + text_len                      # 1332 image positions (36 rows x (36 patches + newline)) + text
     gen = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    patches = torch.randn(B, P, 2700, generator=gen).to(device)
-    ids = torch.randint(10, 262000, (B, S), generator=gen)
     idx = torch.full((B, S), -1, dtype=torch.long)
     for r in range(grid):
         idx[:, r * (grid + 1): r * (grid + 1) + grid] = torch.arange(r * grid, (r + 1) * grid)
-    labels = ids.clone()
-    labels[:, : grid * (grid + 1) + 8] = -100             # the image and the instruction are not targets
-    ids, idx, labels = ids.to(device), idx.to(device), labels.to(device)
+    idx = idx.to(device)
+    # a fresh batch per step, generated up front, resident in HBM when the timed region starts (a repeated batch is memorised in a few steps)
+    n_pool = min(args.steps + args.warmup, 16)
+    pool = []
+    for _ in range(n_pool):
+        patches = torch.randn(B, P, 2700, generator=gen).to(device)
+        ids = torch.randint(10, 262000, (B, S), generator=gen)
+        labels = ids.clone()
+        labels[:, : grid * (grid + 1) + 8] = -100             # the image and the instruction are not targets
+        pool.append((patches, ids.to(device), labels.to(device)))
+    it = [0]
 
     def step():
+        patches, ids, labels = pool[it[0] % n_pool]
+        it[0] += 1
         if reducer is not None:
             reducer.zero_grad()
         else:
@@ -393,12 +402,20 @@ def main():
     B, T = args.batch, args.seq
     from otter_amd.train import masking
 
-    vision_x, ids, amask, labels0, tok_ids = synth_batch(model, B, T, device, seed=1000 + rank, frames=8 if args.config == "c4" else 1)
+    # A FRESH synthetic batch for every step (one repeated batch let the model memorise it and the `loss` field stopped
+    # being a sanity signal): the batches are generated up front and are resident in HBM when the timed region starts (tier brief section 4);
+    # more than 32 steps cycle through the pool.
+    n_pool = min(args.steps + args.warmup, 32)
+    pool = [synth_batch(model, B, T, device, seed=1000 + rank + 7919 * i, frames=8 if args.config == "c4" else 1) for i in range(n_pool)]
+    vision_x, ids, amask, labels0, tok_ids = pool[0]
     batch = (vision_x, ids, amask, labels0)
+    it = [0]
 
     def one_step():
+        vx, tok, am, _, _ = pool[it[0] % n_pool]
+        it[0] += 1
         # the reference builds the labels inside its step (instruction_following.py:163-192): same here, on the device, no host sync
-        return step(vision_x, ids, amask, masking(ids, *tok_ids))
+        return step(vx, tok, am, masking(tok, *tok_ids))
 
     # DIAGNOSTIC (not a valid bench): OTTER_BENCH_OCCUPY_CUS=n parks n workgroups that each pin a whole CU (all of its LDS) on a side stream
     # for the timed region -- what the GEMMs see while a collective's kernel is resident

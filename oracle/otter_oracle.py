@@ -549,9 +549,10 @@ def otter_encode_vision(p, spec, vision_x):
     return vis, c
 
 
-def otter_lm_fwd(p, spec, vis, input_ids, attention_mask=None, past=None, media_locations=None):
+def otter_lm_fwd(p, spec, vis, input_ids, attention_mask=None, past=None, media_locations=None, keep_caches=True):
     """OtterLMMixin.forward + MPTForCausalLM.forward (modeling_otter.py:486-510, modeling_mpt.py:172-305,383-426).
-    Returns (logits, caches, new_past)."""
+    Returns (logits, caches, new_past).  keep_caches=False drops the per-layer backward caches as it goes (forward-only use at
+    the full OTTER-MPT7B size: ~1 GB of fp32 intermediates per layer and sample batch)."""
     LP = "lang_encoder.transformer."
     ids = np.asarray(input_ids)
     if media_locations is None:
@@ -574,16 +575,16 @@ def otter_lm_fwd(p, spec, vis, input_ids, attention_mask=None, past=None, media_
                                           spec.immediate, spec.xattn_heads)
         x, cb, npast = mpt_block_fwd(p, bp + "decoder_layer.", x, spec.n_heads, bias, kp,
                                      past[i] if past else None)
-        caches.append((cx, cb))
+        caches.append((cx, cb) if keep_caches else None)
         new_past.append(npast)
     xf, cf = layer_norm_fwd(x, p[LP + "norm_f.weight"], p.get(LP + "norm_f.bias"))
     logits = xf @ wte.T
     return logits, dict(layers=caches, cf=cf, xf=xf, ids=ids), new_past
 
 
-def otter_forward(p, spec, vision_x, input_ids, attention_mask=None, labels=None):
+def otter_forward(p, spec, vision_x, input_ids, attention_mask=None, labels=None, keep_caches=True):
     vis, cv = otter_encode_vision(p, spec, vision_x)
-    logits, cl, _ = otter_lm_fwd(p, spec, vis, input_ids, attention_mask)
+    logits, cl, _ = otter_lm_fwd(p, spec, vis, input_ids, attention_mask, keep_caches=keep_caches)
     out = dict(logits=logits, vis=vis)
     if labels is not None:
         out["loss"], out["dlogits"] = cross_entropy_rolled(logits, np.asarray(labels))
@@ -619,11 +620,13 @@ def otter_backward(p, spec, out):
     return g
 
 
-def greedy_decode(p, spec, vision_x, input_ids, max_new_tokens, eos_token_id=None, use_cache=False):
+def greedy_decode(p, spec, vision_x, input_ids, max_new_tokens, eos_token_id=None, use_cache=False, trace=None):
     """Greedy loop over OtterLMMixin.forward, restating the behaviour of generate() (modeling_otter.py:999-1042)
     for both decode modes of SURVEY.md section 3.2.  With use_cache=True the step input is the last token only, so
     media_locations is recomputed from that single token (modeling_otter.py:491-492) -> text_time==0 -> the
-    cross-attention output is exactly zero on cached steps (the reference quirk)."""
+    cross-attention output is exactly zero on cached steps (the reference quirk).
+    trace: optional list; per step a dict(top1, top2, margin, absmax) of the last-position logits per sample is appended (how close
+    each greedy choice was -- what a reduced-precision run has to resolve to agree)."""
     vis, _ = otter_encode_vision(p, spec, vision_x)
     ids = np.asarray(input_ids).copy()
     B = ids.shape[0]
@@ -632,12 +635,16 @@ def greedy_decode(p, spec, vision_x, input_ids, max_new_tokens, eos_token_id=Non
     for step in range(max_new_tokens):
         if use_cache:
             if past is None:
-                logits, _, past = otter_lm_fwd(p, spec, vis, ids, None, [() for _ in range(spec.n_layers)])
+                logits, _, past = otter_lm_fwd(p, spec, vis, ids, None, [() for _ in range(spec.n_layers)], keep_caches=False)
             else:
-                logits, _, past = otter_lm_fwd(p, spec, vis, ids[:, -1:], None, past)
+                logits, _, past = otter_lm_fwd(p, spec, vis, ids[:, -1:], None, past, keep_caches=False)
         else:
-            logits, _, _ = otter_lm_fwd(p, spec, vis, ids, None)
+            logits, _, _ = otter_lm_fwd(p, spec, vis, ids, None, keep_caches=False)
         nxt = logits[:, -1, :].argmax(-1)
+        if trace is not None:
+            last = logits[:, -1, :]
+            two = np.sort(np.partition(last, -2, axis=-1)[:, -2:], axis=-1)
+            trace.append(dict(top1=two[:, 1].copy(), top2=two[:, 0].copy(), margin=two[:, 1] - two[:, 0], absmax=np.abs(last).max(-1)))
         if eos_token_id is not None:
             nxt = np.where(done, eos_token_id, nxt)
             done |= nxt == eos_token_id

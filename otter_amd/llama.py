@@ -153,6 +153,8 @@ class LlamaAttention(nn.Module):
         self._qkv = _FusedFrozenLinear([self.q_proj, self.k_proj, self.v_proj])
 
     def flash_ok(self, x, s_past: int, default_positions: bool) -> bool:
+        if any(hasattr(p, "lora_delta") for p in (self.q_proj, self.k_proj, self.v_proj)):
+            return False      # LoRA adapters (otter_amd/lora.py) live in the modules' own forward: the fused q|k|v weight would bypass them
         return (x.is_cuda and OF.compute_dtype_for(x) == torch.bfloat16 and self.head_dim == 128 and self.n_kv == self.n_heads
                 and s_past == 0 and default_positions and self._qkv.usable(x) and os.environ.get("OTTER_NO_FLASH") != "1")
 

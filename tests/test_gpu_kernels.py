@@ -401,25 +401,33 @@ def test_gemm_persistent_blocks_with_several_tiles(ops, variant):
 
 
 BENCH_GEMMS = [
-    # (M, N, K, kind, out dtype): every launch shape of the gated cross-attention block at config C2 (B*T = 4096 tokens, D = 4096,
-    # FFN 16384, inner 512) as pick_cfg dispatches it -- T4 (variant 26) for the FFN shapes, S4 (variant 25) for the projections
-    (4096, 16384, 4096, "gelu", "bf16"),        # FF1 forward: h = gelu(f W1^T), u stored beside it
-    (4096, 4096, 16384, "res", "f32"),          # FF2 forward: y = (h W2^T) tanh(g) + x1, fp32 stream
-    (4096, 16384, 4096, "gate_bwd", "bf16"),    # dU = (dy W2) tanh(g) gelu'(u)
-    (4096, 4096, 16384, "store", "bf16"),       # df = dU W1
-    (16384, 4096, 4096, "store_gate", "f32"),   # dW1 = dU^T f        (fp32 weight gradient)
-    (4096, 16384, 4096, "store_gate", "f32"),   # dW2 = tanh(g) dy^T h (fp32 weight gradient)
-    (4096, 512, 4096, "store", "bf16"),         # to_q
-    (4096, 4096, 512, "res", "f32"),            # to_out + gate + residual
-    (512, 4096, 4096, "store_gate", "f32"),     # dWq
-    (4096, 512, 4096, "store_gate", "f32"),     # dWo
+    # (M, N, K, kind, out dtype, operand layout): every launch of the gated cross-attention block at config C2 (B*T = 4096 tokens, D = 4096,
+    # FFN 16384, inner 512) AS THE BENCHMARK ISSUES IT since round 3 -- T4 (variant 26) for the FFN shapes, S4 (variant 25) for the
+    # projections; "nt" = both operands K-contiguous (otter_gemm_nt: the forward products), "ab" = both K-major (the weight gradients
+    # dW = dy^T x: token rows are the reduction index of both operands as they lie), "b" = B K-major (the input gradients dx = dy W with
+    # W as stored [out, in]).  roofline.by_layout of the bench line counts 320 of 480 FFN-shape launches in the K-major forms.
+    (4096, 16384, 4096, "gelu", "bf16", "nt"),        # FF1 forward: h = gelu(f W1^T), u stored beside it
+    (4096, 4096, 16384, "res", "f32", "nt"),          # FF2 forward: y = (h W2^T) tanh(g) + x1, fp32 stream
+    (4096, 16384, 4096, "gate_bwd", "bf16", "b"),     # dU = (dy W2) tanh(g) gelu'(u), W2 [4096, 16384] as stored = [K][N]
+    (4096, 4096, 16384, "store", "bf16", "b"),        # df = dU W1, W1 [16384, 4096] as stored
+    (16384, 4096, 4096, "store", "f32", "ab"),        # dW1 = dU^T f        (fp32 weight gradient; dU [tokens, 16384], f [tokens, 4096])
+    (4096, 16384, 4096, "store_gate", "f32", "ab"),   # dW2 = tanh(g) dy^T h (fp32 weight gradient with the gate folded in)
+    (4096, 16384, 4096, "gate_bwd", "bf16", "nt"),    # round-2 forms of the same four products (OTTER_NO_KMAJOR=1, and what C4 / C5 fall
+    (4096, 4096, 16384, "store", "bf16", "nt"),       # back to when a shape is not K-major capable): transposed copies + otter_gemm_nt
+    (16384, 4096, 4096, "store_gate", "f32", "nt"),
+    (4096, 16384, 4096, "store_gate", "f32", "nt"),
+    (4096, 512, 4096, "store", "bf16", "nt"),         # to_q
+    (4096, 4096, 512, "res", "f32", "nt"),            # to_out + gate + residual
+    (512, 4096, 4096, "store_gate", "f32", "nt"),     # dWq
+    (4096, 512, 4096, "store_gate", "f32", "nt"),     # dWo
 ]
 
 
-@pytest.mark.parametrize("M,N,Kd,kind,out_dt", BENCH_GEMMS)
-def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt):
-    """the kernels the benchmark times, at the benchmark's shapes, with the fused tails and the fp32-output
-    weight-gradient form -- default dispatch (variant 0).  A full fp64 product of 4096 x 16384 x 4096 is too slow for the host, so:
+@pytest.mark.parametrize("M,N,Kd,kind,out_dt,layout", BENCH_GEMMS)
+def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt, layout):
+    """the kernels the benchmark times, at the benchmark's shapes AND operand layouts, with the fused tails
+    and the fp32-output weight-gradient form -- default dispatch (variant 0).  The K-major launches are judged against the fp64 product
+    like the others (not against the K-contiguous kernel).  A full fp64 product of 4096 x 16384 x 4096 is too slow for the host, so:
     (a) 96 sampled rows and 96 sampled columns (incl. first / last of every 256-tile edge) against the fp64 product of those rows /
     columns; (b) a checksum over EVERY element through linearity: C 1 = A (B^T 1) for the plain store (fp64 on the host, O(MK + NK))."""
     from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
@@ -427,7 +435,17 @@ def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt):
     r = rng(M // 7 + N + Kd)
     A = bf16_round(r.standard_normal((M, Kd)).astype(np.float32) * 0.25)
     B = bf16_round(r.standard_normal((N, Kd)).astype(np.float32) * 0.25)
-    dA, dB = to_dev(A, torch.bfloat16), to_dev(B, torch.bfloat16)
+    ta, tb = layout == "ab", layout in ("ab", "b")
+    # a K-major operand is handed over as it lies in the backward pass: [K rows][M or N columns]
+    dA = to_dev(np.ascontiguousarray(A.T) if ta else A, torch.bfloat16)
+    dB = to_dev(np.ascontiguousarray(B.T) if tb else B, torch.bfloat16)
+    if ta or tb:
+        assert ops.gemm_kmajor_supported(M, N, Kd, dA.stride(0), dB.stride(0), ta, tb, torch.bfloat16)
+    _nt = ops.gemm_nt
+
+    def gemm_nt(a, b, **kw):
+        return _nt(a, b, a_kmajor=ta, b_kmajor=tb, **kw)
+
     odt = torch.bfloat16 if out_dt == "bf16" else torch.float32
     gate = np.array([0.6], np.float32)
     s = float(np.tanh(0.6))
@@ -444,10 +462,10 @@ def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt):
         assert relmax(Ch[:, cols], f(acc_c, slice(None), cols)) < tol_
 
     if kind == "store":
-        C = ops.gemm_nt(dA, dB, out_dtype=odt)
+        C = gemm_nt(dA, dB, out_dtype=odt)
         check(C, lambda a, i, j: a)
     elif kind == "store_gate":
-        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_STORE, gate=to_dev(gate))
+        C = gemm_nt(dA, dB, out_dtype=odt, kind=EPI_STORE, gate=to_dev(gate))
         check(C, lambda a, i, j: a * s)
         # checksum of every element: row sums of C == s * A (sum_n B[n, :])
         rs = host(C).astype(np.float64).sum(1)
@@ -455,22 +473,22 @@ def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt):
         assert np.abs(rs - want).max() < 1e-3 * np.abs(want).max() + 1e-3 * np.sqrt(N)
     elif kind == "gelu":
         C2 = torch.empty((M, N), dtype=odt, device=DEV)
-        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GELU, C2=C2)
+        C = gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GELU, C2=C2)
         check(C2, lambda a, i, j: a)
         check(C, lambda a, i, j: O.gelu_fwd(a))
     elif kind == "res":
         R = r.standard_normal((M, N)).astype(np.float32)
-        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_SCALE_RES, gate=to_dev(gate), R=to_dev(R))
+        C = gemm_nt(dA, dB, out_dtype=odt, kind=EPI_SCALE_RES, gate=to_dev(gate), R=to_dev(R))
         check(C, lambda a, i, j: a * s + R[i, j].astype(np.float64))
     else:
         aux = bf16_round(r.standard_normal((M, N)).astype(np.float32))
         part = torch.zeros(ops.gemm_num_partials(M, N, torch.bfloat16), dtype=torch.float32, device=DEV)
-        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GATE_BWD, gate=to_dev(gate), aux=to_dev(aux, torch.bfloat16), aux_gelu=True, partial=part)
+        C = gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GATE_BWD, gate=to_dev(gate), aux=to_dev(aux, torch.bfloat16), aux_gelu=True, partial=part)
         check(C, lambda a, i, j: s * a * O.gelu_grad(aux[i, j].astype(np.float64)))
         # the gate gradient = (1 - s^2) sum(acc * gelu(aux)) over EVERY element: against an independent fp32 product (torch / rocBLAS on
         # the same device, fp64 reduction) -- the per-tile partials + reduce kernel see all 64 M accumulators
         dg = float(ops.reduce_partials(part, gate=to_dev(gate))[0])
-        acc_t = torch.matmul(dA.float(), dB.float().t())
+        acc_t = torch.matmul(dA.float().t() if ta else dA.float(), dB.float() if tb else dB.float().t())
         want = float((acc_t.double() * torch.nn.functional.gelu(to_dev(aux).double())).sum()) * (1 - s * s)
         scale = float((acc_t.double() * torch.nn.functional.gelu(to_dev(aux).double())).abs().sum()) * (1 - s * s)
         assert abs(dg - want) < 1e-5 * scale + 1e-3

@@ -126,3 +126,19 @@ def test_mpt_attention_core():
         assert G.rel_err(O._merge_heads(dq), gold[f"{tag}_dq"]) < 1e-4
         assert G.rel_err(O._merge_heads(dk), gold[f"{tag}_dk"]) < 1e-4
         assert G.rel_err(O._merge_heads(dv), gold[f"{tag}_dv"]) < 1e-4
+
+
+def test_greedy_trace_and_cache_free_forward_options():
+    """The options the full-size GPU parity test (tests/test_gpu_full_model.py) uses: greedy_decode(trace=...) reports the top-2 margin of
+    every step without changing the tokens; otter_forward(keep_caches=False) returns the same logits / loss."""
+    m, p, spec = _tiny()
+    gold = G.load("otter_tiny")
+    vision_x, ids, mask, labels = synth.tiny_batch(m["seed"])
+    trace = []
+    toks = O.greedy_decode(p, spec, vision_x, ids[:, :8], 6, use_cache=False, trace=trace)
+    assert np.array_equal(toks, gold["greedy_nocache"]) and len(trace) == 6
+    for t in trace:
+        assert t["margin"].shape == (ids.shape[0],) and (t["margin"] >= 0).all() and np.allclose(t["top1"] - t["top2"], t["margin"])
+    a = O.otter_forward(p, spec, vision_x, ids, mask, labels)
+    b = O.otter_forward(p, spec, vision_x, ids, mask, labels, keep_caches=False)
+    assert np.array_equal(a["logits"], b["logits"]) and a["loss"] == b["loss"]
