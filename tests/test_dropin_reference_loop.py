@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-REF = "/root/reference"
+REF = os.environ.get("OTTER_REF_ROOT", "/root/reference")     # (the GPU leg stages the five pipeline/train files elsewhere: tools/stage_reference_loop.sh)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pipeline", "train")), reason="needs the reference checkout (build container)")
