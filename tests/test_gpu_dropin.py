@@ -20,7 +20,10 @@ _staged = os.path.join(ROOT, "oracle", "_ref", "reference_loop")
 if "OTTER_REF_ROOT" not in os.environ and os.path.isdir(os.path.join(_staged, "pipeline", "train")):
     os.environ["OTTER_REF_ROOT"] = _staged
 
-from tests import test_dropin_reference_loop as D  # noqa: E402  (reads OTTER_REF_ROOT at import)
+from tests import test_dropin_reference_loop as D  # noqa: E402
+
+if not os.path.isdir(os.path.join(D.REF, "pipeline", "train")) and os.path.isdir(os.path.join(_staged, "pipeline", "train")):
+    D.REF = _staged      # (pytest may have imported the CPU module, with its default root, before this one)
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.isdir(os.path.join(D.REF, "pipeline", "train")),
                                                   reason="needs the reference's pipeline/train (tools/stage_reference_loop.sh)")]

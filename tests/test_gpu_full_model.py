@@ -32,8 +32,13 @@ from tests import _golden as G  # noqa: E402
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 NEW_TOKENS = 8
-# bf16 production mode, stated tolerances (measured figures: DESIGN.md section 5 / profiles/r04_full_model_parity.jsonl)
-BF16_ROW_TOL, BF16_COS_MIN, BF16_LOSS_TOL = 3e-2, 0.9995, 1e-2
+# bf16 production mode, stated tolerances.  Measured on MI355X (profiles/r04_run1_parity_metrics.jsonl):
+#   C1  fp32 mode: logits 4.4e-6 (max) / 4.3e-6 (per row), loss 1.7e-7, greedy ids bit-exact in both decode modes
+#   C1  bf16 mode: logits 8.5e-3 per row, cosine 0.99997, loss 2.2e-4, 8 / 8 greedy tokens agree in both modes
+#                  (fp32 top-2 margins of the eight steps: 0.8 % .. 7.6 % of the largest logit)
+#   C2 (B = 2) bf16 forward: logits 9.2e-3 per row, cosine 0.99997, loss 2.7e-5
+# -> tolerance = about 2x the measured figure.
+BF16_ROW_TOL, BF16_COS_MIN, BF16_LOSS_TOL = 2e-2, 0.9999, 2e-3
 
 
 def _host_state(model):

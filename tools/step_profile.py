@@ -7,7 +7,7 @@ import bench
 from otter_amd.train import TrainStep
 
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-needle = sys.argv[2] if len(sys.argv) > 2 else "CUDAFunctor_add"
+needles = sys.argv[2:] if len(sys.argv) > 2 else ["CUDAFunctor_add"]
 dev = torch.device("cuda:0")
 model = bench.build_model(dev, 0, debug_layers=layers)
 batch = bench.synth_batch(model, 8, 512, dev, 0)[:4]
@@ -19,16 +19,18 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(*batch)
     torch.cuda.synchronize()
-agg = collections.Counter()
-tot = collections.Counter()
-for e in prof.events():
-    if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::"):
-        kern = [k for k in e.kernels if needle in k.name]
-        if not kern:
-            continue
-        stack = [f for f in (e.stack or []) if "otter_amd" in f or "bench.py" in f or "torch/autograd" in f][:3]
-        key = (e.name, str(e.input_shapes)[:80], " <- ".join(s.split("/")[-1] for s in stack) or "(no py frame: autograd engine)")
-        agg[key] += len(kern)
-        tot[key] += sum(k.duration for k in kern)
-for key, n in agg.most_common(12):
-    print(n, round(tot[key]), "us", key)
+for needle in needles:
+    agg = collections.Counter()
+    tot = collections.Counter()
+    for e in prof.events():
+        if e.device_type == torch.autograd.DeviceType.CPU and e.name.startswith("aten::"):
+            kern = [k for k in e.kernels if needle in k.name]
+            if not kern:
+                continue
+            stack = [f for f in (e.stack or []) if "otter_amd" in f or "bench.py" in f or "torch/autograd" in f][:3]
+            key = (e.name, str(e.input_shapes)[:80], " <- ".join(s.split("/")[-1] for s in stack) or "(no py frame: autograd engine)")
+            agg[key] += len(kern)
+            tot[key] += sum(k.duration for k in kern)
+    print("=== kernels matching %r: %d launches, %.0f us per step" % (needle, sum(agg.values()), sum(tot.values())))
+    for key, n in sorted(agg.items(), key=lambda kv: -tot[kv[0]])[:14]:
+        print("  ", n, round(tot[key]), "us", key)
