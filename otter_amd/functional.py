@@ -242,6 +242,41 @@ def add_layer_norm(x, delta, weight, bias, eps=1e-5, out_dtype=None):
     return AddLayerNormFn.apply(x, delta, weight, bias, eps, out_dtype or x.dtype)
 
 
+class ForkLayerNormFn(torch.autograd.Function):
+    """(x, y) = (x, LN(x)) for a residual stream that is read by the norm AND carried on (mpt/blocks.py:77-84 `a = norm_1(x); ...; x = x + b`).
+    As two autograd nodes the stream's gradient arrives twice and the engine adds the two [rows, D] fp32 tensors in a separate pass
+    (29 us per decoder layer that follows a gated block at C2); here the carried-on gradient enters the LayerNorm backward as its
+    residual term (`dres`): one pass.  The first output is the input itself (same storage)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, weight.detach() if weight is not None else None,
+                                          bias.detach() if bias is not None else None, out_dtype, eps)
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        ctx.shp = shp
+        return x.view(shp), y.view(shp)
+
+    @staticmethod
+    def backward(ctx, d_x, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        need_dw = weight is not None and weight.requires_grad
+        D = ctx.shp[-1]
+        dres = d_x.reshape(-1, D).contiguous() if d_x is not None else None
+        if dres is not None and dres.dtype != x2.dtype:
+            dres = dres.to(x2.dtype)
+        dx, dg, db = ops.layernorm_bwd(dy.reshape(-1, D).contiguous(), x2, weight.detach() if weight is not None else None, mean, rstd,
+                                       x2.dtype, dres=dres, need_dw=need_dw, need_dbeta=ctx.has_bias)
+        return (dx.view(ctx.shp), dg.to(weight.dtype) if dg is not None else None,
+                db.to(weight.dtype) if (db is not None and ctx.has_bias) else None, None, None)
+
+
+def fork_layer_norm(x, weight, bias, eps=1e-5, out_dtype=None):
+    return ForkLayerNormFn.apply(x, weight, bias, eps, out_dtype or x.dtype)
+
+
 class RMSNormFn(torch.autograd.Function):
     """LlamaRMSNorm (xformers_model/llama.py:95-112 / HF): y = w * (x * rsqrt(mean(x^2) + eps)).to(x.dtype), config C4."""
 
@@ -644,7 +679,10 @@ class GatedCrossAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, media, tt, mask_mode, heads, eps, norm_w, norm_b, Wq, Wkv, Wo, attn_gate, ffn_w, ffn_b, W1, W2,
-                ff_gate):
+                ff_gate, delta=None):
+        """delta (otter_amd extension, round 4): the previous decoder layer's un-added FFN output (bf16 [B,T,D]); the block then
+        starts from x + delta, the add fused into its first LayerNorm pass (mpt.py hands its residual adds to the NEXT norm; before
+        round 4 a gated block forced a separate fp32 add + a bf16 cast of its gradient: 45 us per block at C2)."""
         B, T, D = x.shape
         _, T_img, n, Dv = media.shape
         inner = Wq.shape[0]
@@ -657,7 +695,10 @@ class GatedCrossAttentionFn(torch.autograd.Function):
         scale = HEAD_DIM ** -0.5
         ga, gf = _flat_gate(attn_gate), _flat_gate(ff_gate)
         # --- masked cross attention ---
-        xn, mean1, rstd1 = ops.layernorm_fwd(x2, norm_w.detach(), norm_b.detach(), cd, eps)
+        if delta is not None:
+            x2, xn, mean1, rstd1 = ops.add_layernorm_fwd(x2, delta.reshape(N, D).contiguous(), norm_w.detach(), norm_b.detach(), cd, eps)
+        else:
+            xn, mean1, rstd1 = ops.layernorm_fwd(x2, norm_w.detach(), norm_b.detach(), cd, eps)
         q = ops.gemm_nt(xn, shadows.w(Wq, cd))
         med = ops.cast(media.reshape(B * M, Dv).contiguous(), cd)
         kv = ops.gemm_nt(med, shadows.w(Wkv, cd))                                   # [B*M, 2*inner]
@@ -675,6 +716,7 @@ class GatedCrossAttentionFn(torch.autograd.Function):
             ctx.save_for_backward(x2, xn, mean1, rstd1, q, kv, o2, lse, x1, mean2, rstd2, f, u, h, med, tt, norm_w, Wq, Wkv,
                                   Wo, attn_gate, ffn_w, W1, W2, ff_gate)
             ctx.meta = (B, T, D, T_img, n, Dv, inner, heads, mask_mode, scale, cd, rd, media.dtype)
+            ctx.delta_dtype = delta.dtype if delta is not None else None
         return y.view(B, T, D)
 
     @staticmethod
@@ -712,7 +754,15 @@ class GatedCrossAttentionFn(torch.autograd.Function):
         dmedia = None
         if ctx.needs_input_grad[1]:
             dmedia = ops.gemm_nt(dkv2, shadows.wt(Wkv, cd), out_dtype=media_dtype).view(B, T_img, n, Dv)
-        dx, dg1, db1 = ops.layernorm_bwd(dxn, x2, norm_w.detach(), mean1, rstd1, rd, dres=dx1)
+        # the gradient of a deferred delta is dx in delta's dtype: written by the same LayerNorm-backward pass when that is bf16
+        ddelta = None
+        want_dd = ctx.delta_dtype is not None and ctx.needs_input_grad[17]
+        fused_dd = want_dd and ctx.delta_dtype == torch.bfloat16 and rd == torch.float32
+        if fused_dd:
+            ddelta = torch.empty((N, D), dtype=torch.bfloat16, device=dev)
+        dx, dg1, db1 = ops.layernorm_bwd(dxn, x2, norm_w.detach(), mean1, rstd1, rd, dres=dx1, dx_bf16=ddelta)
+        if want_dd and not fused_dd:
+            ddelta = dx if ctx.delta_dtype == dx.dtype else ops.cast(dx, ctx.delta_dtype)
 
         def pg(g, p):
             if g is None:  # already delivered through the grad sink
@@ -721,7 +771,7 @@ class GatedCrossAttentionFn(torch.autograd.Function):
 
         return (dx.view(B, T, D), dmedia, None, None, None, None, pg(dg1, norm_w), pg(db1, norm_w), pg(dWq, Wq), pg(dWkv, Wkv),
                 pg(dWo, Wo), pg(d_attn_gate, attn_gate), pg(dg2, ffn_w), pg(db2, ffn_w), pg(dW1, W1), pg(dW2, W2),
-                pg(d_ff_gate, ff_gate))
+                pg(d_ff_gate, ff_gate), ddelta.view(B, T, D) if ddelta is not None else None)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

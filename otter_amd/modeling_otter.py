@@ -197,6 +197,8 @@ class OtterMaskedCrossAttention(nn.Module):
 
 
 class OtterGatedCrossAttentionBlock(nn.Module):
+    accepts_deferred = True      # forward(..., deferred=): see OtterLayer.forward / otter_amd.mpt._gated_takes_deferred
+
     def __init__(self, *, dim: int, dim_visual: int, dim_head: int = 64, heads: int = 8, ff_mult: int = 4,
                  only_attend_immediate_media: bool = True):
         super().__init__()
@@ -207,7 +209,9 @@ class OtterGatedCrossAttentionBlock(nn.Module):
                                            nn.Linear(dim * ff_mult, dim, bias=False)])
         self.ff_gate = nn.Parameter(torch.tensor([0.0]))
 
-    def forward(self, x, media, media_locations=None, attend_previous: bool = True, text_time=None):
+    def forward(self, x, media, media_locations=None, attend_previous: bool = True, text_time=None, deferred=None):
+        """`deferred` (otter_amd extension): an addend of the residual stream that has not been added yet (the MPT host hands each
+        block's FFN output to the NEXT LayerNorm pass); the block computes on x + deferred, the add fused into its first LayerNorm."""
         a, ff = self.attn, self.feed_forward
         mode = _mask_mode(media_locations, a.only_attend_immediate_media)
         tt = text_time
@@ -215,7 +219,7 @@ class OtterGatedCrossAttentionBlock(nn.Module):
             tt = ops.text_time(media_locations, attend_previous)
         return OF.GatedCrossAttentionFn.apply(x, media, tt, mode, a.heads, a.norm.eps, a.norm.weight, a.norm.bias, a.to_q.weight,
                                               a.to_kv.weight, a.to_out.weight, self.attn_gate, ff[0].weight, ff[0].bias,
-                                              ff[1].weight, ff[3].weight, self.ff_gate)
+                                              ff[1].weight, ff[3].weight, self.ff_gate, deferred)
 
 
 class OtterLayer(nn.Module):
@@ -252,8 +256,15 @@ class OtterLayer(nn.Module):
             raise ValueError("vis_x must be conditioned before forward pass")
         if self.media_locations is None:
             raise ValueError("media_locations must be conditioned before forward pass")
+        # otter_amd's MPT host may hand over the previous layer's FFN output un-added (`deferred`, mpt.py): the gated block fuses the add
+        # into its first LayerNorm; the decoder layer then starts from the block's (materialised) output, which it both normalises and
+        # carries on (`fork_input`: one LayerNorm-backward pass instead of an extra gradient add)
+        deferred = decoder_layer_kwargs.pop("deferred", None)
+        gkw = {"deferred": deferred} if deferred is not None else {}
         lang_x = self.gated_cross_attn_layer(lang_x, self.vis_x, media_locations=self.media_locations,
-                                             attend_previous=self.attend_previous, text_time=self.text_time)
+                                             attend_previous=self.attend_previous, text_time=self.text_time, **gkw)
+        if "defer_out" in decoder_layer_kwargs:       # (only otter_amd's MPTBlock takes the extension keywords)
+            decoder_layer_kwargs["fork_input"] = True
         return self.decoder_layer(lang_x, attention_mask=attention_mask, **decoder_layer_kwargs)
 
 

@@ -100,6 +100,10 @@ class _Norm(nn.LayerNorm):
         """(x + delta, LN(x + delta)) fused in one HIP pass over the residual stream."""
         return OF.add_layer_norm(x, delta, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
 
+    def fork_forward(self, x):
+        """(x, LN(x)) as ONE autograd node: the gradient of the carried-on stream enters the LayerNorm backward as its residual term."""
+        return OF.fork_layer_norm(x, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
+
 
 def _own_gemm() -> bool:
     """OTTER_OWN_DECODER_GEMM=1: every GEMM of the frozen decoder on csrc/gemm.hip instead of hipBLASLt: fused
@@ -256,12 +260,14 @@ class MPTBlock(nn.Module):
         self.ffn = MPTMLP(config.d_model, config.expansion_ratio, bias)
 
     def forward(self, x, past_key_value=None, attn_bias=None, attention_mask=None, is_causal=True, deferred=None,
-                defer_out=False, flash=None, decode=None):
+                defer_out=False, flash=None, decode=None, fork_input=False):
         """`deferred` / `defer_out` (otter_amd extension, used by MPTModel.forward): the FFN output of a block is handed to
         the NEXT block un-added, where the residual add is fused into that block's norm_1 pass (one trip over the fp32
         residual stream instead of two).  With the defaults this is exactly mpt/blocks.py:68-88."""
         if deferred is not None:
             x, a = self.norm_1.add_forward(x, deferred)   # x = x + ffn_out(prev) ; a = norm_1(x)
+        elif fork_input and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+            x, a = self.norm_1.fork_forward(x)            # same values; the stream's two gradients meet inside the LayerNorm backward
         else:
             a = self.norm_1(x)
         b, past_key_value = self.attn(a, past_key_value=past_key_value, attn_bias=attn_bias, is_causal=is_causal, flash=flash, decode=decode)
@@ -270,6 +276,14 @@ class MPTBlock(nn.Module):
         if defer_out:
             return x, None, past_key_value, n
         return x + n, None, past_key_value
+
+
+def _gated_takes_deferred(block, x, delta) -> bool:
+    """otter_amd.modeling_otter.OtterLayer forwards `deferred` to its gated cross-attention block, which fuses x + deferred into its first
+    LayerNorm pass (HIP path: GPU tensors, fp32 stream + bf16 addend or equal dtypes).  OTTER_NO_DEFER_INTO_GATED=1: A/B switch."""
+    g = getattr(block, "gated_cross_attn_layer", None)
+    return (g is not None and getattr(g, "accepts_deferred", False) and x.is_cuda and delta.is_cuda
+            and os.environ.get("OTTER_NO_DEFER_INTO_GATED") != "1")
 
 
 class MPTPreTrainedModel(PreTrainedModel):
@@ -389,8 +403,8 @@ class MPTModel(MPTPreTrainedModel):
         delta = None
         for i, block in enumerate(self.blocks):
             pkv = past_key_values[i] if past_key_values is not None else None
-            if delta is not None and getattr(block, "gated_cross_attn_layer", None) is not None:
-                x = x + delta
+            if delta is not None and getattr(block, "gated_cross_attn_layer", None) is not None and not _gated_takes_deferred(block, x, delta):
+                x = x + delta       # (a wrapper that cannot take the un-added addend gets the materialised sum)
                 delta = None
             out = block(x, past_key_value=pkv, attn_bias=attn_bias, attention_mask=None, is_causal=self.is_causal,
                         deferred=delta, defer_out=True, flash=flash, decode=decode)

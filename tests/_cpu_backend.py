@@ -50,6 +50,9 @@ class GatedCrossAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, media, tt, mask_mode, heads, eps, *params):
         assert abs(eps - 1e-5) < 1e-12
+        ctx.extra = len(params) - len(GatedCrossAttentionFn.NAMES)      # the product passes `deferred` (None on the CPU: mpt._gated_takes_deferred)
+        assert ctx.extra in (0, 1) and all(t is None for t in params[len(GatedCrossAttentionFn.NAMES):])
+        params = params[:len(GatedCrossAttentionFn.NAMES)]
         p = {"b." + n: _np(t) for n, t in zip(GatedCrossAttentionFn.NAMES, params)}
         y, c = O.gated_xattn_block_fwd(p, "b.", _np(x), _np(media), None, True, mask_mode == MASK_EQ, heads,
                                        tt=None if mask_mode == MASK_NONE else tt.cpu().numpy())
@@ -61,7 +64,7 @@ class GatedCrossAttentionFn(torch.autograd.Function):
     def backward(ctx, dy):
         dx, dmedia, g = O.gated_xattn_block_bwd(ctx.p, "b.", _np(dy), ctx.c)
         grads = [_route(t, g["b." + n], t) for n, t in zip(GatedCrossAttentionFn.NAMES, ctx.params)]
-        return (torch.from_numpy(dx).to(ctx.dtypes[0]), torch.from_numpy(dmedia).to(ctx.dtypes[1]), None, None, None, None, *grads)
+        return (torch.from_numpy(dx).to(ctx.dtypes[0]), torch.from_numpy(dmedia).to(ctx.dtypes[1]), None, None, None, None, *grads, *([None] * ctx.extra))
 
 
 class PerceiverBlockFn(torch.autograd.Function):

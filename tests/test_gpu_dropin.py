@@ -62,6 +62,9 @@ def test_reference_train_one_epoch_on_the_hip_kernels(ref_script, precision, tmp
                                  remove_answer_token=False, remove_eos_token=False, mask_lm_head=False, distributed_type="NO",
                                  report_to_wandb=False, save_steps_interval=-1, logging_steps=1, num_epochs=1, external_save_dir=str(tmp_path),
                                  save_hf_model=False)
+    from accelerate.state import AcceleratorState
+
+    AcceleratorState._reset_state(reset_partial_state=True)      # the state is a process-wide singleton: the other precision's leg set it
     accelerator = Accelerator(gradient_accumulation_steps=1, mixed_precision=precision)
     assert accelerator.device.type == "cuda"
     lr, wd = 1e-3, 0.1
