@@ -461,117 +461,10 @@ void norm_bwd_dx_c_kernel(const bf16_t* __restrict__ dy, otter_rowmap dymap, con
         }
 }
 
-// ---- round 4: dx AND the dgamma / dbeta partials in ONE pass over x and dy ----
-// The separate column-parallel pass (norm_bwd_dw_partial_kernel) re-reads x (fp32) and dy (bf16): 96 MB at the C2 shape, 21 us + 11 us for
-// the final reduction, for every LayerNorm with trainable parameters (two per gated block, twelve in the perceiver).  Here a workgroup is
-// EIGHT waves = eight rows; phase 1 is norm_bwd_dx_c_kernel's; in phase 2, per 512-column chunk, every wave stores its row's contributions
-// (dy and dy * x-hat, the values it has just used for dx) into a [wave][2][512] LDS stage, one barrier later thread j adds column j of the
-// eight rows (fixed order: deterministic) into two registers per chunk.  The stage is double-buffered, so ONE barrier per chunk orders
-// both the hand-over and the reuse (a wave can only pass barrier c + 1 after it has finished reading chunk c).  At the end a workgroup
-// writes ONE partial row pair (rows / 8 pairs in all, 16 MB at C2: written + read once by the final kernel, against the 96 MB re-read).
-template <int NCH, bool RMS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4)))
-void norm_bwd_dxdw_c_kernel(const bf16_t* __restrict__ dy, otter_rowmap dymap, const float* __restrict__ x, const void* __restrict__ gamma, int wdt,
-                            const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dres, float* __restrict__ dx,
-                            bf16_t* __restrict__ dx2, float* __restrict__ part, int rows, int D) {
-    __shared__ __attribute__((aligned(16))) float stage[2][8][2][512];   // 64 KB: [buffer][wave][dy | dy * x-hat][column of the chunk]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = (int)blockIdx.x * 8 + wave;
-    const bool live = row < rows;                       // (every wave takes every barrier; a wave past the last row contributes zeros)
-    const int nrun = D >> 9;
-    const float mu = (RMS || !live) ? 0.f : mean[row];
-    const float rs = live ? rstd[row] : 0.f;
-    // 32-bit element offsets (the launcher checks rows * D < 2^31): scalar base + one VGPR offset per access instead of 64-bit pointers
-    const uint32_t base = (uint32_t)(live ? row : 0) * (uint32_t)D + (uint32_t)lane * 4u;
-    const uint32_t dbase = (uint32_t)(live ? map_row(row, dymap) : 0) * (uint32_t)D + (uint32_t)lane * 4u;
-    float xr[NCH][2][4];
-    uint2 dr[NCH][2];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-        if (c < nrun) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (live) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(x + (base + c * 512 + h * 256));
-                    xr[c][h][0] = t4.x; xr[c][h][1] = t4.y; xr[c][h][2] = t4.z; xr[c][h][3] = t4.w;
-                    dr[c][h] = *reinterpret_cast<const uint2*>(dy + (dbase + c * 512 + h * 256));
-                } else {
-                    xr[c][h][0] = xr[c][h][1] = xr[c][h][2] = xr[c][h][3] = 0.f;
-                    dr[c][h] = make_uint2(0u, 0u);
-                }
-            }
-        }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-        if (c < nrun) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float gm[4];
-                if (gamma) ld4(gamma, c * 512 + h * 256 + lane * 4, wdt, gm);
-                const float dv[4] = {__uint_as_float(dr[c][h].x << 16), __uint_as_float(dr[c][h].x & 0xffff0000u),
-                                     __uint_as_float(dr[c][h].y << 16), __uint_as_float(dr[c][h].y & 0xffff0000u)};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float t = (xr[c][h][i] - mu) * rs;
-                    const float gg = gamma ? dv[i] * gm[i] : dv[i];
-                    s1 += gg;
-                    s2 += gg * t;
-                }
-            }
-        }
-    const float m1 = RMS ? 0.f : wave_sum(s1) / (float)D;
-    const float m2 = wave_sum(s2) / (float)D;
-    // partial rows in norm_bwd_dw_partial_kernel's layout: [chunk of rows][dgamma | dbeta][D]
-    const uint32_t pofs = (uint32_t)blockIdx.x * 2u * (uint32_t)D + threadIdx.x;
-#pragma unroll
-    for (int c = 0; c < NCH; ++c)
-        if (c < nrun) {
-            float(*st)[2][512] = stage[c & 1];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t o = base + c * 512 + h * 256;
-                float gm[4], r[4], out[4], cg[4];
-                if (gamma) ld4(gamma, c * 512 + h * 256 + lane * 4, wdt, gm);
-                if (dres && live) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(dres + o);
-                    r[0] = t4.x; r[1] = t4.y; r[2] = t4.z; r[3] = t4.w;
-                }
-                const float dv[4] = {__uint_as_float(dr[c][h].x << 16), __uint_as_float(dr[c][h].x & 0xffff0000u),
-                                     __uint_as_float(dr[c][h].y << 16), __uint_as_float(dr[c][h].y & 0xffff0000u)};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float t = (xr[c][h][i] - mu) * rs;
-                    const float gg = gamma ? dv[i] * gm[i] : dv[i];
-                    float u = (gg - m1 - t * m2) * rs;
-                    if (dres && live) u += r[i];
-                    out[i] = u;
-                    cg[i] = dv[i] * t;
-                }
-                if (live) {
-                    *reinterpret_cast<float4*>(dx + o) = make_float4(out[0], out[1], out[2], out[3]);
-                    if (dx2) {
-                        uint2 pk;
-                        pk.x = pack2bf(out[0], out[1]);
-                        pk.y = pack2bf(out[2], out[3]);
-                        *reinterpret_cast<uint2*>(dx2 + o) = pk;
-                    }
-                }
-                *reinterpret_cast<float4*>(&st[wave][0][h * 256 + lane * 4]) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                *reinterpret_cast<float4*>(&st[wave][1][h * 256 + lane * 4]) = make_float4(cg[0], cg[1], cg[2], cg[3]);
-            }
-            __syncthreads();
-            float sb = 0.f, sg = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                sb += st[w][0][threadIdx.x];
-                sg += st[w][1][threadIdx.x];
-            }
-            part[pofs + c * 512] = sg;           // this thread's column of the chunk, summed over the workgroup's eight rows
-            part[pofs + (uint32_t)D + c * 512] = sb;
-        }
-}
-
+// (Round 4 tried dx AND the dgamma / dbeta partials in one pass -- eight rows per workgroup, contributions folded through a double-buffered
+//  LDS stage, one barrier per 512-column chunk: correct (same tests), but 82.6 us against 67.6 us for the two passes below at the C2 stream
+//  shape (tools/norm_bench.py, `ln_bwd_dres_dw`): the chunk barriers line the eight waves' loads up, and the dx pass alone already streams
+//  at 5.9 TB/s.  The two-pass form stays; the experiment is commit 635b55c "LayerNorm backward: dx + dgamma/dbeta partials in one pass".)
 // OTTER_NORM_VARIANT (read once): 0 = generic kernels only, 1 (default) = coalesced kernels where they apply
 int norm_variant() {
     static int v = -1;
@@ -631,25 +524,7 @@ int launch_bwd(const void* dy, int dydt, otter_rowmap dymap, const void* x, int 
     OTTER_REQUIRE(dy && x && rstd && rows > 0, "norm_bwd: null pointer or empty shape");
     OTTER_REQUIRE(D % 8 == 0 && D <= 8192, "norm_bwd: D=%ld must be a multiple of 8 and <= 8192", (long)D);
     const int nch = pick_nch(D);
-    const bool coalesced = dx && norm_variant() >= 1 && xdt == OTTER_F32 && dydt == OTTER_BF16 && dxdt == OTTER_F32 && D % 512 == 0 && nch <= 8;
-    if (coalesced && dgamma && ws && norm_variant() != 2 && rows >= 64 && rows * D < (int64_t(1) << 31) && cdiv64(rows, 8) * 2 * D < (int64_t(1) << 31)) {
-        // round 4: dx and the dgamma / dbeta partials from one pass (OTTER_NORM_VARIANT=2 keeps the two-pass form for A/B runs)
-        const int rch = (int)cdiv64(rows, 8);
-        dim3 grid((unsigned)rch), block(512);
-#define LF(N) hipLaunchKernelGGL((norm_bwd_dxdw_c_kernel<N, RMS>), grid, block, 0, st, (const bf16_t*)dy, dymap, (const float*)x, gamma, wdt, mean, rstd, (const float*)dres, (float*)dx, dx2, (float*)ws, (int)rows, (int)D)
-        switch (nch) {
-            case 1: LF(1); break;
-            case 2: LF(2); break;
-            case 4: LF(4); break;
-            default: LF(8); break;
-        }
-#undef LF
-        OTTER_CHECK_LAUNCH("norm_bwd_dxdw_c");
-        hipLaunchKernelGGL(norm_bwd_dw_final_kernel, dim3((unsigned)cdiv64(D, 64)), dim3(256), 0, st, (const float*)ws, dgamma,
-                           dbeta, (int)D, rch, accumulate);
-        OTTER_CHECK_LAUNCH("norm_bwd_dw_final");
-        return OTTER_OK;
-    }
+    const bool coalesced = dx && norm_variant() == 1 && xdt == OTTER_F32 && dydt == OTTER_BF16 && dxdt == OTTER_F32 && D % 512 == 0 && nch <= 8;
     if (coalesced) {
         dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
 #define LC(N) hipLaunchKernelGGL((norm_bwd_dx_c_kernel<N, RMS>), grid, block, 0, st, (const bf16_t*)dy, dymap, (const float*)x, gamma, wdt, mean, rstd, (const float*)dres, (float*)dx, dx2, rows, (int)D)
@@ -708,11 +583,7 @@ int otter_add_layernorm_fwd(const void* x, int x_dtype, const void* delta, int d
                              (hipStream_t)stream, delta, delta_dtype, xsum);
 }
 
-int64_t otter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) {
-    // the fused dx + dw pass writes one partial row pair per eight rows; the two-pass form one per row chunk (pick_rch)
-    const int64_t pairs = cdiv64(rows, 8) > pick_rch(rows) ? cdiv64(rows, 8) : pick_rch(rows);
-    return pairs * 2 * D * 4;
-}
+int64_t otter_layernorm_bwd_workspace_bytes(int64_t rows, int64_t D) { return (int64_t)pick_rch(rows) * 2 * D * 4; }
 
 int otter_layernorm_bwd(const void* dy, int dy_dtype, otter_rowmap dy_map, const void* x, int x_dtype, const void* gamma,
                         int w_dtype, const float* mean, const float* rstd, const void* dres, void* dx, int dx_dtype,

@@ -137,6 +137,44 @@ def _wgrad(dyT: torch.Tensor, xT: torch.Tensor, gate=None, param=None):
     return ops.gemm_nt(dyT, xT, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
 
 
+class _SideStream:
+    """A second HIP stream per device for the HALF-CHIP launches of the fusion modules (round 4).  The skinny projections of a gated block
+    (to_q, dO, dWo, dWq: 4096 x 512 x 4096 in some order) are 128 workgroups of one workgroup per CU: half of the MI355X's 256 CUs idle for
+    ~40 us each.  Two of them that do not depend on each other are issued on two streams and share the chip.  Protocol (all inside one
+    autograd Function call): fork() makes the side stream wait for everything issued so far on the current stream; work is launched inside
+    `with side.ctx():` (ops.* read torch's current stream); join() makes the current stream wait for the side stream.  Tensors handed
+    from one stream to the other are kept alive by the caller until after join(); outputs consumed on the main stream are allocated on
+    the main stream BEFORE the fork.  OTTER_NO_SIDE_STREAM=1: everything on one stream (A/B switch)."""
+
+    _streams = {}
+
+    def __init__(self, device):
+        self.enabled = device.type == "cuda" and os.environ.get("OTTER_NO_SIDE_STREAM") != "1"
+        self.forked = False
+        if self.enabled:
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            st = _SideStream._streams.get(key)
+            if st is None:
+                st = _SideStream._streams[key] = torch.cuda.Stream(device=device)
+            self.side = st
+
+    def fork(self):
+        if self.enabled:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self.forked = True
+        return self
+
+    def ctx(self):
+        import contextlib
+
+        return torch.cuda.stream(self.side) if (self.enabled and self.forked) else contextlib.nullcontext()
+
+    def join(self):
+        if self.enabled and self.forked:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.forked = False
+
+
 def _wgrad_rows(dy_rows: torch.Tensor, x_rows: torch.Tensor, gate=None, param=None):
     """dW[out,in] = (s *) dy^T . x from the operands AS THEY LIE in HBM -- dy [rows, out], x [rows, in], compute dtype -- through the
     K-major GEMM (csrc/gemm.hip, transpose reads inside the kernel) when the shape qualifies; otherwise the operands are transposed
@@ -699,9 +737,18 @@ class GatedCrossAttentionFn(torch.autograd.Function):
             x2, xn, mean1, rstd1 = ops.add_layernorm_fwd(x2, delta.reshape(N, D).contiguous(), norm_w.detach(), norm_b.detach(), cd, eps)
         else:
             xn, mean1, rstd1 = ops.layernorm_fwd(x2, norm_w.detach(), norm_b.detach(), cd, eps)
-        q = ops.gemm_nt(xn, shadows.w(Wq, cd))
-        med = ops.cast(media.reshape(B * M, Dv).contiguous(), cd)
-        kv = ops.gemm_nt(med, shadows.w(Wkv, cd))                                   # [B*M, 2*inner]
+        # the media projection (32 tiles) beside the query projection (128 tiles, half the chip): two streams
+        med_in = media.reshape(B * M, Dv).contiguous()
+        med = med_in if med_in.dtype == cd else torch.empty((B * M, Dv), dtype=cd, device=x.device)
+        kv = torch.empty((B * M, Wkv.shape[0]), dtype=cd, device=x.device)          # [B*M, 2*inner]
+        wkv_c, wq_c = shadows.w(Wkv, cd), shadows.w(Wq, cd)
+        side = _SideStream(x.device).fork()
+        with side.ctx():
+            if med is not med_in:
+                ops.K.check(ops.K.lib().otter_cast(med_in.data_ptr(), ops.K.dt(med_in), med.data_ptr(), ops.K.dt(med), med_in.numel(), ops.K.stream()), "cast")
+            ops.gemm_nt(med, wkv_c, out=kv)
+        q = ops.gemm_nt(xn, wq_c)
+        side.join()
         kv3 = kv.view(B, M, 2 * inner)
         o, lse = ops.attn_fwd(q.view(B, T, inner), kv3[..., :inner], kv3[..., inner:], heads, tt, n, mask_mode, scale)
         o2 = o.view(N, inner)
@@ -739,18 +786,40 @@ class GatedCrossAttentionFn(torch.autograd.Function):
         df = _dgrad(dU, W1, cd)
         dx1, dg2, db2 = ops.layernorm_bwd(df, x1, ffn_w.detach(), mean2, rstd2, rd, dres=dy2)
         # ---- attention branch:  x1 = (o Wo^T) tanh(ga) + x ----
+        # Two streams (see _SideStream): the weight gradients of the skinny projections (128 workgroups each = half the chip) run beside
+        # the chain that produces dx -- dWo beside dO + the attention backward, dWq / dWkv beside dxn + the LayerNorm backward.
         dx1T, dx1_cd = ops.transpose(dx1, cd, want_same=True)
+        sink = grad_sink
+
+        def wgrad_out(param):       # the sink's bucket view, or a fresh fp32 tensor allocated on THIS stream (consumed here after the join)
+            out = sink.take(param) if sink is not None else None
+            return (out, True) if out is not None else (torch.empty(param.shape, dtype=torch.float32, device=dev), False)
+
+        dWo_out, dWo_sunk = wgrad_out(Wo)
+        side = _SideStream(dev).fork()
+        with side.ctx():
+            o2T = ops.transpose(o2, cd)
+            ops.gemm_nt(dx1T, o2T, out=dWo_out, kind=EPI_STORE, gate=ga)
         part2 = torch.empty(ops.gemm_num_partials(N, inner, cd), dtype=torch.float32, device=dev)
         dO = ops.gemm_nt(dx1_cd, shadows.wt(Wo, cd), kind=EPI_GATE_BWD, gate=ga, aux=o2, aux_gelu=False, partial=part2)
         d_attn_gate = ops.reduce_partials(part2, gate=ga)
-        dWo = _wgrad(dx1T, ops.transpose(o2, cd), gate=ga, param=Wo)
         kv3 = kv.view(B, M, 2 * inner)
         dq, dkv = ops.attn_bwd(q.view(B, T, inner), kv3[..., :inner], kv3[..., inner:], o2.view(B, T, inner),
                                dO.view(B, T, inner), lse, heads, tt, n, mask_mode, scale)
         dq2, dkv2 = dq.view(N, inner), dkv.view(B * M, 2 * inner)
-        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(xn, cd), param=Wq)
+        side.join()
+        if dWo_sunk:
+            sink.ready(Wo)          # (on the main stream, after the join: the reducer orders its collective behind THIS stream)
+        dWo = None if dWo_sunk else dWo_out
+        dWq_out, dWq_sunk = wgrad_out(Wq)
+        dWkv_out, dWkv_sunk = wgrad_out(Wkv)
+        side.fork()
+        with side.ctx():
+            dq2T, xnT = ops.transpose(dq2, cd), ops.transpose(xn, cd)
+            ops.gemm_nt(dq2T, xnT, out=dWq_out, kind=EPI_STORE)
+            dkv2T, medT = ops.transpose(dkv2, cd), ops.transpose(med, cd)
+            ops.gemm_nt(dkv2T, medT, out=dWkv_out, kind=EPI_STORE)
         dxn = ops.gemm_nt(dq2, shadows.wt(Wq, cd))
-        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(med, cd), param=Wkv)
         dmedia = None
         if ctx.needs_input_grad[1]:
             dmedia = ops.gemm_nt(dkv2, shadows.wt(Wkv, cd), out_dtype=media_dtype).view(B, T_img, n, Dv)
@@ -763,6 +832,12 @@ class GatedCrossAttentionFn(torch.autograd.Function):
         dx, dg1, db1 = ops.layernorm_bwd(dxn, x2, norm_w.detach(), mean1, rstd1, rd, dres=dx1, dx_bf16=ddelta)
         if want_dd and not fused_dd:
             ddelta = dx if ctx.delta_dtype == dx.dtype else ops.cast(dx, ctx.delta_dtype)
+        side.join()
+        for prm, sunk in ((Wq, dWq_sunk), (Wkv, dWkv_sunk)):
+            if sunk:
+                sink.ready(prm)
+        dWq = None if dWq_sunk else dWq_out
+        dWkv = None if dWkv_sunk else dWkv_out
 
         def pg(g, p):
             if g is None:  # already delivered through the grad sink

@@ -80,9 +80,8 @@ def test_layernorm_fwd_bwd(ops, rows, D, dt):
 
 @pytest.mark.parametrize("rows,D", [(37, 512), (130, 1024), (70, 4096), (4097, 1536), (4096, 4096), (67, 3584)])
 def test_norm_training_config_vs_oracle(ops, rows, D):
-    """The coalesced row kernels (fp32 stream, bf16 branch tensors, D % 512 == 0: norm_fwd_c / norm_bwd_dx_c_kernel, and -- round 4, rows >= 64 with
-    weight gradients -- the fused norm_bwd_dxdw_c_kernel: dx and the dgamma / dbeta partials from one pass, eight rows per workgroup, incl. row
-    counts that are not multiples of eight and the C2 stream shape) against the oracle:
+    """The coalesced row kernels (fp32 stream, bf16 branch tensors, D % 512 == 0: norm_fwd_c / norm_bwd_dx_c_kernel; incl. the C2 stream shape and
+    row counts that are not multiples of four) against the oracle:
     LayerNorm forward (plain, with fused residual add, through a row map + second output), backward with and without the residual
     gradient / bf16 copy / weight gradients; RMSNorm forward + backward.  Tolerances: bf16 outputs 1e-2, fp32 results 5e-5."""
     from otter_amd._capi import RowMap

@@ -28,7 +28,7 @@ t = bench(lambda: ops.add_layernorm_fwd(x, delta, g, b, torch.bfloat16)); out["a
 t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, torch.float32, dres=dres, need_dw=False)); out["ln_bwd_dres"] = [round(t, 1), round(MB * 14 / t, 2)]
 t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, torch.float32, dres=dres, need_dw=False, dx_bf16=dxb)); out["ln_bwd_dres_bf16copy"] = [round(t, 1), round(MB * 16 / t, 2)]
 t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, torch.float32, need_dw=False)); out["ln_bwd"] = [round(t, 1), round(MB * 10 / t, 2)]
-t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, torch.float32, dres=dres, need_dw=True)); out["ln_bwd_dres_dw"] = [round(t, 1), round(MB * 14 / t, 2)]   # variant 1: fused dx + dw pass; variant 2: dx pass + column pass
+t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, torch.float32, dres=dres, need_dw=True)); out["ln_bwd_dres_dw"] = [round(t, 1), round(MB * 14 / t, 2)]
 t = bench(lambda: ops.layernorm_bwd(dy, x, g, mean, rstd, torch.float32, need_dw=True, need_dx=False)); out["ln_bwd_dw_only"] = [round(t, 1), round(MB * 6 / t, 2)]
 t = bench(lambda: ops.colsum(dy, None, R)); out["colsum_bf16"] = [round(t, 1), round(MB * 2 / t, 2)]
 print(json.dumps(out))
