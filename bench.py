@@ -265,18 +265,23 @@ def cpu_baseline(T=512):
               "time = 8*gated + 32*mpt + perceiver + 24*clip + unembed (optimizer/all-reduce not included)"
               % (t["gated_block"], t["mpt_block"], t["perceiver"], t["clip_layer"], t["unembed_loss"]))
     out = {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
-    # calibration of the numpy port against the REFERENCE's own modules (torch CPU fp32), measured once in the build container where
-    # /root/reference exists (oracle/calibrate_cpu_baseline.py -> profiles/r03_cpu_baseline_calibration.json; it cannot travel to this box)
-    cal = os.path.join(ROOT, "profiles", "r03_cpu_baseline_calibration.json")
-    if os.path.exists(cal):
+    # calibration of the numpy port against the REFERENCE's own modules (torch CPU fp32, oracle/calibrate_cpu_baseline.py).  The reference
+    # cannot be on this box during a driver run; round 4 measured the ratio ON A GPU NODE's own host cores once (staged scratch copy,
+    # tools/stage_reference_loop.sh stage-models -> profiles/r04_cpu_baseline_calibration_gpu_node.json); the build container's 8-thread
+    # figure (profiles/r03_cpu_baseline_calibration.json) is the fallback.
+    for name, where in (("r04_cpu_baseline_calibration_gpu_node.json", "a GPU node of this pool (%d host threads)"), ("r03_cpu_baseline_calibration.json", "the build container (%d threads)")):
+        cal = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(cal):
+            continue
         with open(cal) as f:
             c = json.load(f)
         r = c["step_mix"]["port_vs_reference"]
         out["port_vs_reference"] = round(r, 3)
         out["reference_equivalent_value"] = round(out["value"] / r, 5)
-        out["calibration"] = ("the reference's own modules (gated block, 6-layer perceiver, MPT block; fwd+bwd, fp32, %d threads, build container) run the "
-                              "same sample in %.2fx the time of the numpy port: reference-equivalent rate = value / port_vs_reference"
-                              % (c["host_threads"], r))
+        out["calibration"] = ("the reference's own modules (gated block, 6-layer perceiver, MPT block; fwd+bwd, fp32, torch CPU) run the same sample in "
+                              "%.2fx the time of the numpy port on %s: reference-equivalent rate = value / port_vs_reference"
+                              % (r, where % c["host_threads"]))
+        break
     return out
 
 

@@ -1,7 +1,10 @@
 """Calibrates bench.py's `cpu_baseline` (kind "port" = the numpy oracle) against the REFERENCE's own modules on the same host, same
-sample, same thread count.  Build container only (needs /root/reference, which cannot travel to the GPU box):
+sample, same thread count.  Needs the reference's model sources: /root/reference in the build container (8 threads), or -- round 4 -- an
+uncommitted scratch copy staged under oracle/_ref/ for ONE gpurun call, so that the ratio is measured on the GPU NODE's own host cores
+(tools/stage_reference_loop.sh stage-models; OTTER_REF_ROOT points at it):
 
-    python oracle/calibrate_cpu_baseline.py        ->  profiles/r03_cpu_baseline_calibration.json
+    python oracle/calibrate_cpu_baseline.py [out.json]     ->  profiles/r03_cpu_baseline_calibration.json (build container)
+                                                                profiles/r04_cpu_baseline_calibration_gpu_node.json (GPU node)
 
 Timed (1 pair: 1 x 224^2 image worth of latents + 512 tokens, fp32, forward + backward, min of 3 after a warm-up):
   * OtterGatedCrossAttentionBlock(dim=4096, dim_visual=1024)      reference: src/otter_ai/models/otter/modeling_otter.py:343-395
@@ -24,7 +27,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from oracle import otter_oracle as O  # noqa: E402
 from oracle import synth  # noqa: E402
-from oracle.gen_golden import import_reference  # noqa: E402
+from oracle.gen_golden import REF, import_reference  # noqa: E402
 
 
 def best(fn, n=3):
@@ -94,7 +97,7 @@ def main():
     del per, pp
 
     # ---- frozen MPT block: forward + input gradient ----
-    sys.path.insert(0, "/root/reference")
+    sys.path.insert(0, REF)
     from src.otter_ai.models.mpt.blocks import MPTBlock  # type: ignore
     from src.otter_ai.models.mpt.attention import build_alibi_bias, build_attn_bias  # type: ignore
 
@@ -126,7 +129,8 @@ def main():
     out["step_mix"] = {"reference_s": ref_t, "port_s": port_t, "port_vs_reference": ref_t / port_t}
     for k in ("gated_block", "perceiver", "mpt_block"):
         out[k]["port_vs_reference"] = out[k]["reference_s"] / out[k]["port_s"]
-    dst = os.path.join(ROOT, "profiles", "r03_cpu_baseline_calibration.json")
+    out["reference_root"] = "staged scratch copy (GPU node)" if "OTTER_REF_ROOT" in os.environ else REF
+    dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_cpu_baseline_calibration.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from oracle import synth  # noqa: E402
 
-REF = "/root/reference"
+REF = os.environ.get("OTTER_REF_ROOT", "/root/reference")   # (a staged scratch copy on the GPU box: tools/stage_reference_loop.sh stage-models)
 OUT = os.path.join(ROOT, "tests", "golden")
 
 

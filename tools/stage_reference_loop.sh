@@ -12,6 +12,15 @@ case "$1" in
     mkdir -p "$dst/pipeline/train"
     for f in __init__.py instruction_following.py train_args.py train_utils.py distributed.py; do cp "$src/$f" "$dst/pipeline/train/$f"; done
     echo "staged -> $dst (remove with: $0 clean)";;
+  stage-models)
+    # the reference's own model modules, for oracle/calibrate_cpu_baseline.py ON THE GPU NODE (cpu_baseline calibrated on its host cores)
+    src=/root/reference/src/otter_ai/models
+    [ -d "$src" ] || { echo "no $src (build container only)"; exit 1; }
+    for d in otter mpt mpt_redpajama falcon; do
+      mkdir -p "$dst/src/otter_ai/models/$d"
+      cp "$src/$d"/*.py "$dst/src/otter_ai/models/$d/"
+    done
+    echo "staged models -> $dst (OTTER_REF_ROOT=$dst; remove with: $0 clean)";;
   clean) rm -rf "$dst"; echo "removed $dst";;
-  *) echo "usage: $0 stage|clean"; exit 2;;
+  *) echo "usage: $0 stage|stage-models|clean"; exit 2;;
 esac
