@@ -72,6 +72,18 @@ def build_gemm_define(define: str, suffix: str, verbose: bool = True) -> str:
     return out
 
 
+def build_flash_define(define: str, suffix: str, verbose: bool = True) -> str:
+    """A/B build of flash.hip with one extra -D (e.g. OTTER_FLASH_SAFE_DMA) -> lib/libotter_hip_<suffix>.so (tools only, via OTTER_LIB_PATH)."""
+    build(verbose=verbose)
+    cc = hipcc()
+    obj = os.path.join(LIBDIR, "flash_%s.o" % suffix)
+    out = os.path.join(LIBDIR, "libotter_hip_%s.so" % suffix)
+    subprocess.check_call([cc, *FLAGS, "-D" + define, "-c", os.path.join(CSRC, "flash.hip"), "-o", obj])
+    others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != "flash.hip"]
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
+    return out
+
+
 def build_flash_timing(verbose: bool = True) -> str:
     """Diagnostics build with the in-kernel timeline of the flash forward (-DOTTER_FLASH_TIMING) ->
     lib/libotter_hip_flashtiming.so; only tools/flash_timeline.py loads it."""
@@ -117,6 +129,9 @@ if __name__ == "__main__":
     if "--define" in sys.argv:
         i = sys.argv.index("--define")
         print(build_gemm_define(sys.argv[i + 1], sys.argv[i + 2]))
+    elif "--flash-define" in sys.argv:
+        i = sys.argv.index("--flash-define")
+        print(build_flash_define(sys.argv[i + 1], sys.argv[i + 2]))
     elif "--experimental" in sys.argv:
         print(build_experimental())
     elif "--flash-timing" in sys.argv:

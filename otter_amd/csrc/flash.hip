@@ -52,6 +52,7 @@ struct FlashArgs {
     bf16_t* dq; bf16_t* dk; bf16_t* dv; Str dqs, dks, dvs;
     int lpt_group;         // heads (PAIR: head pairs) per group of the longest-first block order (divides the number of (b, head) blocks)
     int pair;              // head_dim 64: two heads per workgroup (the PAIR instantiations)
+    int fuse_delta;        // round 4: the dQ kernel computes delta = rowsum(dO . O) and the log2 LSE itself and publishes them for dK/dV (no flash_delta launch)
 };
 
 // In-kernel timeline of workgroup (3,0,0) / wave 0 of the forward (diagnostics build only: -DOTTER_FLASH_TIMING)
@@ -321,6 +322,12 @@ __device__ __forceinline__ u32x4_t make_rsrc4(const void* p, uint32_t bytes) {
     return r;
 }
 __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+// Round 4: the LEAN form of csrc/gemm.hip (s_mov m0; s_nop 0; buffer_load ... lds).  M0 is clobbered, not saved / restored: hipcc never keeps
+// a value in M0 across statements (every compiler-generated use is preceded by its own s_mov), and nothing else in these kernels uses it.
+// The descriptor is built once in the prologue (the v_readfirstlane -> buffer-descriptor hazard is long past) and soffset comes from scalar
+// arithmetic.  Per piece 3 instructions instead of 6 + a 5-cycle s_nop: with one or two waves per SIMD every instruction beside an MFMA
+// is an issue slot (-DOTTER_FLASH_SAFE_DMA restores the save / settle / restore form for an A/B build).
+#ifdef OTTER_FLASH_SAFE_DMA
 __device__ __forceinline__ void dma16_asm(u32x4_t r, const char* lds, uint32_t voff, uint32_t soff) {
     unsigned keep;
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -331,6 +338,14 @@ __device__ __forceinline__ void dma4_asm(u32x4_t r, const char* lds, uint32_t vo
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+#else
+__device__ __forceinline__ void dma16_asm(u32x4_t r, const char* lds, uint32_t voff, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma4_asm(u32x4_t r, const char* lds, uint32_t voff, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+#endif
 
 __device__ __forceinline__ void flash_dma_tile(u32x4_t rk, u32x4_t rv, char* kdst, char* vdst,
                                                const uint32_t (&vk)[4], const uint32_t (&vv)[4], int wave, uint32_t ksoff,
@@ -559,14 +574,19 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
                 const int jj = k0 + lane;
                 vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * h2);
             }
+            // round 4: visibility of the lane's 32 keys as ONE 64-bit word (causal / sequence-end limit ANDed with the key-padding bits), then
+            // v_bfe_i32 + v_bfi_b32 per score -- the head-pair kernels' form -- instead of a 64-bit shift, two compares and a select per score
+            // (the diagonal tiles are 2 of the 2-8 tiles of every block at S = 512)
+            const unsigned long long okm = limh < 0 ? 0ull : (limh >= 63 ? vmh : vmh & ((2ull << limh) - 1ull));
+            const unsigned okm_lo = (unsigned)okm, okm_hi = (unsigned)(okm >> 32);
 #pragma unroll
             for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
                     float x = fmaf(s[kbk][r], sc2, fmaf(sl2, (float)cidx, base));
-                    const bool ok = cidx <= limh && ((vmh >> cidx) & 1ull);
-                    x = ok ? x : -INFINITY;
+                    const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)(cidx < 32 ? okm_lo : okm_hi), cidx & 31, 1);
+                    x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, x) & mk) | (~mk & 0xFF800000u));
                     s[kbk][r] = x;
                     mx = fmaxf(mx, x);
                 }
@@ -949,8 +969,42 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
     }
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
     const int64_t srow = ((int64_t)b * a.H + hd * hm) * a.Sq + qc;
-    const float lse2 = qi < a.Sq ? a.delta[nrows + srow] : INFINITY, dl = a.delta[srow];
-    const float lse2B = PAIR ? (qi < a.Sq ? a.delta[nrows + srow + a.Sq] : INFINITY) : 0.f, dlB = PAIR ? a.delta[srow + a.Sq] : 0.f;
+    float lse2, dl, lse2B = 0.f, dlB = 0.f;
+    if (a.fuse_delta) {
+        // delta[q] = sum_d dO[q, d] O[q, d] from the dO fragments this lane already holds and the matching O fragments (the lane pair
+        // ql / ql + 32 covers a row: one cross-half add), and the log2-domain LSE; written out for the dK/dV kernel, which runs AFTER this
+        // one in that mode.  Replaces the flash_delta launch (18 us per layer at C2: 67 MB read for 1 MB of results).
+        const bf16_t* op = a.o + b * a.os.b + hd * hm * a.os.h + (int64_t)qc * a.os.s;
+        const int64_t opo = PAIR ? a.os.h - 64 : 0;
+        float accA = 0.f, accB = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(op + 16 * c + 8 * h2 + (c >= 4 ? opo : 0));
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t = fmaf(static_cast<float>(dof[c][i]), static_cast<float>(of[i]), t);
+            if (PAIR && c >= 4) accB += t; else accA += t;
+        }
+        accA += __shfl_xor(accA, 32, 64);
+        const float lA = a.lse[srow];
+        dl = accA;
+        lse2 = qi < a.Sq ? (lA == -INFINITY ? INFINITY : lA * LOG2E) : INFINITY;
+        if (PAIR) {
+            accB += __shfl_xor(accB, 32, 64);
+            const float lB = a.lse[srow + a.Sq];
+            dlB = accB;
+            lse2B = qi < a.Sq ? (lB == -INFINITY ? INFINITY : lB * LOG2E) : INFINITY;
+        }
+        if (h2 == 0 && qi < a.Sq) {
+            a.delta[srow] = dl;
+            a.delta[nrows + srow] = lse2;
+            if (PAIR) { a.delta[srow + a.Sq] = dlB; a.delta[nrows + srow + a.Sq] = lse2B; }
+        }
+    } else {
+        lse2 = qi < a.Sq ? a.delta[nrows + srow] : INFINITY;
+        dl = a.delta[srow];
+        if (PAIR) { lse2B = qi < a.Sq ? a.delta[nrows + srow + a.Sq] : INFINITY; dlB = a.delta[srow + a.Sq]; }
+    }
     const bf16_t* kb = a.k + b * a.ks.b + hd * hm * a.ks.h;
     const bf16_t* vb = a.v + b * a.vs.b + hd * hm * a.vs.h;
     const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
@@ -1076,11 +1130,15 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
                     s[r] = p * (dp[r] - dl);
                 }
             } else {
+                // (round 4: one visibility word per lane and tile, v_bfe_i32 + v_and_b32 per score: see the forward)
+                const unsigned long long okm = limh < 0 ? 0ull : (limh >= 63 ? vmh : vmh & ((2ull << limh) - 1ull));
+                const unsigned okm_lo = (unsigned)okm, okm_hi = (unsigned)(okm >> 32);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int cidx = 32 * kbk + (r & 3) + 8 * (r >> 2);
-                    const bool ok = cidx <= limh && ((vmh >> cidx) & 1ull);
-                    const float p = ok ? __builtin_amdgcn_exp2f(fmaf(s[r], sc2, fmaf(sl2, (float)cidx, base))) : 0.f;
+                    float p = __builtin_amdgcn_exp2f(fmaf(s[r], sc2, fmaf(sl2, (float)cidx, base)));
+                    const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)(cidx < 32 ? okm_lo : okm_hi), cidx & 31, 1);
+                    p = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, p) & mk);
                     s[r] = p * (dp[r] - dl);
                 }
             }
@@ -1595,7 +1653,7 @@ int set_smem(K kern, int bytes) {
 extern "C" {
 
 int otter_flash_set_variant(int v) {
-    OTTER_REQUIRE(v >= 0 && v <= 5, "flash variant %d (0 = default: LDS-DMA v2, LPT block order; 1 = register-staged v1; 2 = v2, plain grid; 3 = 2 + dK/dV at two workgroups per CU; 4 = 0; 5 = 0 + dK/dV at two workgroups per CU)", v);
+    OTTER_REQUIRE(v >= 0 && v <= 5, "flash variant %d (0 = default: LDS-DMA v2, LPT block order, delta inside the dQ kernel; 1 = register-staged v1; 2 = v2, plain grid; 3 = 2 + dK/dV at two workgroups per CU; 4 = 0 with the separate flash_delta launch (round-3 order); 5 = 0 + dK/dV at two workgroups per CU)", v);
     g_flash_variant = v;
     return OTTER_OK;
 }
@@ -1657,12 +1715,17 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
-    if (a.pair) hipLaunchKernelGGL(flash_delta_kernel<8>, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(flash_delta_kernel<16>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, st, a);
-    OTTER_CHECK_LAUNCH("flash_delta");
     const int64_t lim = int64_t(1) << 31;
     const bool v2 = g_flash_variant != 1 && (int64_t)a.Sk * a.ks.s * 2 < lim && (int64_t)a.Sk * a.vs.s * 2 < lim &&
                     (int64_t)a.Sq * a.qs.s * 2 < lim && (int64_t)a.Sq * a.dos.s * 2 < lim;
+    // round 4: on the LDS-DMA kernels the dQ kernel computes delta / the log2 LSE itself and runs FIRST (dK/dV reads what it published);
+    // variant 4 keeps the separate flash_delta launch and the old order (A/B)
+    a.fuse_delta = (v2 && g_flash_variant != 4) ? 1 : 0;
+    if (!a.fuse_delta) {
+        if (a.pair) hipLaunchKernelGGL(flash_delta_kernel<8>, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(flash_delta_kernel<16>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, st, a);
+        OTTER_CHECK_LAUNCH("flash_delta");
+    }
     OTTER_REQUIRE(v2 || !a.pair, "flash: head_dim 64 only on the LDS-DMA kernels (variant != 1, panels under 2 GB)");
     if (v2 && a.pair) {
         const int smem_kv = 49152 + 1536, smem_q = 65536 + KMASK_TILES * 8;
@@ -1677,17 +1740,21 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
             once = true;
         }
         const unsigned nkb = (unsigned)((a.Sk + 127) / 128), nqb = (unsigned)((a.Sq + 127) / 128), hb = (unsigned)(a.H / 2);
-        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, true>), dim3(nkb * hb * a.B), dim3(256), smem_kv, st, a);
-        else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, true>), dim3(nkb, hb, a.B), dim3(256), smem_kv, st, a);
-        OTTER_CHECK_LAUNCH("flash_bwd_dkv");
-        if (a.slopes) {
-            if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true, true>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
-            else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true, true>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
-        } else {
-            if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true, false>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
-            else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true, false>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
-        }
-        OTTER_CHECK_LAUNCH("flash_bwd_dq");
+        auto launch_dkv = [&]() {
+            if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, true>), dim3(nkb * hb * a.B), dim3(256), smem_kv, st, a);
+            else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, true>), dim3(nkb, hb, a.B), dim3(256), smem_kv, st, a);
+        };
+        auto launch_dq = [&]() {
+            if (a.slopes) {
+                if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true, true>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
+                else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true, true>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
+            } else {
+                if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, true, false>), dim3(nqb * hb * a.B), dim3(256), smem_q, st, a);
+                else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, true, false>), dim3(nqb, hb, a.B), dim3(256), smem_q, st, a);
+            }
+        };
+        if (a.fuse_delta) { launch_dq(); OTTER_CHECK_LAUNCH("flash_bwd_dq"); launch_dkv(); OTTER_CHECK_LAUNCH("flash_bwd_dkv"); }
+        else { launch_dkv(); OTTER_CHECK_LAUNCH("flash_bwd_dkv"); launch_dq(); OTTER_CHECK_LAUNCH("flash_bwd_dq"); }
         return OTTER_OK;
     }
     if (v2) {
@@ -1707,15 +1774,19 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
             once = true;
         }
         const unsigned nkb = (unsigned)((a.Sk + 127) / 128);
-        if (g_flash_variant == 3) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
-        else if (flash_lpt(a) && g_flash_variant != 5) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
-        else if (g_flash_variant == 5 && a.causal) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
-        else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
-        OTTER_CHECK_LAUNCH("flash_bwd_dkv");
         const unsigned nqb = (unsigned)((a.Sq + 127) / 128);
-        if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, false, true>), dim3(nqb * a.H * a.B), dim3(256), smem_q, st, a);
-        else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, false, true>), dim3(nqb, a.H, a.B), dim3(256), smem_q, st, a);
-        OTTER_CHECK_LAUNCH("flash_bwd_dq");
+        auto launch_dkv = [&]() {
+            if (g_flash_variant == 3) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
+            else if (flash_lpt(a) && g_flash_variant != 5) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
+            else if (g_flash_variant == 5 && a.causal) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
+            else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
+        };
+        auto launch_dq = [&]() {
+            if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dq2_kernel<true, false, true>), dim3(nqb * a.H * a.B), dim3(256), smem_q, st, a);
+            else hipLaunchKernelGGL((flash_bwd_dq2_kernel<false, false, true>), dim3(nqb, a.H, a.B), dim3(256), smem_q, st, a);
+        };
+        if (a.fuse_delta) { launch_dq(); OTTER_CHECK_LAUNCH("flash_bwd_dq"); launch_dkv(); OTTER_CHECK_LAUNCH("flash_bwd_dkv"); }
+        else { launch_dkv(); OTTER_CHECK_LAUNCH("flash_bwd_dkv"); launch_dq(); OTTER_CHECK_LAUNCH("flash_bwd_dq"); }
         return OTTER_OK;
     }
     const int smem_kv = (2 * 32 * LDK + 2 * 32 * LDT) * 2 + 64 * 4;
