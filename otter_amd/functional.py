@@ -875,8 +875,14 @@ class PerceiverBlockFn(torch.autograd.Function):
         _, mean_m, rstd_m = ops.layernorm_fwd(x2, nm_w.detach(), nm_b.detach(), cd, eps, y=kv_in, ymap=RowMap(n1, nk, 0))
         ln = torch.empty((G * n2, D), dtype=cd, device=x.device)
         _, mean_l, rstd_l = ops.layernorm_fwd(l2, nl_w.detach(), nl_b.detach(), cd, eps, y=kv_in, ymap=RowMap(n2, nk, n1), y2=ln)
-        q = ops.gemm_nt(ln, shadows.w(Wq, cd))                                     # [G*n2, inner]
-        kv = ops.gemm_nt(kv_in, shadows.w(Wkv, cd))                                # [G*nk, 2*inner]
+        # to_q (16 tiles at C2) beside to_kv (160 tiles): two streams, see _SideStream -- every GEMM of the resampler is a small grid
+        q = torch.empty((G * n2, inner), dtype=cd, device=x.device)                # [G*n2, inner]
+        wq_c, wkv_c = shadows.w(Wq, cd), shadows.w(Wkv, cd)
+        side = _SideStream(x.device).fork()
+        with side.ctx():
+            ops.gemm_nt(ln, wq_c, out=q)
+        kv = ops.gemm_nt(kv_in, wkv_c)                                             # [G*nk, 2*inner]
+        side.join()
         kv3 = kv.view(G, nk, 2 * inner)
         o, lse = ops.attn_fwd(q.view(G, n2, inner), kv3[..., :inner], kv3[..., inner:], heads, None, 1, MASK_NONE, scale)
         o2 = o.view(G * n2, inner)
@@ -899,23 +905,50 @@ class PerceiverBlockFn(torch.autograd.Function):
         G, n1, n2, D, inner, heads, scale, cd, rd, xdtype = ctx.meta
         nk = n1 + n2
         dy2 = dy.reshape(G * n2, D).contiguous()
+        # Round 4: the five weight gradients (and the operand transposes they need at these small-grid shapes) run on a SECOND STREAM beside
+        # the chain that produces dx / dlatents -- every GEMM of the resampler is 16-160 workgroups on 256 CUs and 15-30 us of latency, so the
+        # two streams share the chip instead of queueing (see _SideStream; the side stream re-synchronises with this one before each
+        # product whose operands were produced here, and is joined before the function returns).
+        dev = dy.device
+        sink = grad_sink
+        side = _SideStream(dev)
+        sunk = []
+
+        def wgrad_side(dy_rows, x_rows, param, fork=True):
+            """dW[out,in] = dy_rows^T . x_rows on the side stream, into the sink's bucket view or a tensor allocated on THIS stream."""
+            out = sink.take(param) if sink is not None else None
+            if out is not None:
+                sunk.append(param)
+            else:
+                out = torch.empty(param.shape, dtype=torch.float32, device=dev)
+            if fork:
+                side.fork()
+            with side.ctx():
+                rows, n_out = dy_rows.shape
+                if (os.environ.get("OTTER_NO_KMAJOR") != "1"
+                        and ops.gemm_kmajor_supported(n_out, x_rows.shape[1], rows, dy_rows.stride(0), x_rows.stride(0), True, True, dy_rows.dtype)):
+                    ops.gemm(dy_rows, x_rows, True, True, out=out, kind=EPI_STORE)
+                else:
+                    ops.gemm_nt(ops.transpose(dy_rows, cd), ops.transpose(x_rows, cd), out=out, kind=EPI_STORE)
+            return None if (sunk and sunk[-1] is param) else out
+
         # feed-forward: y = gelu(f W1^T) W2^T + out1
         dy_cd = dy2 if dy2.dtype == cd else ops.cast(dy2, cd)
+        dW2 = wgrad_side(dy_cd, h, W2)
         dU = _dgrad(dy_cd, W2, cd, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
-        dW2 = _wgrad_rows(dy_cd, h, param=W2)
-        dW1 = _wgrad_rows(dU, f, param=W1)
+        dW1 = wgrad_side(dU, f, W1)
         df = _dgrad(dU, W1, cd)
         dout1, dgf, dbf = ops.layernorm_bwd(df, out1, ff_w.detach(), mean_f, rstd_f, rd, dres=dy2)
         # attention: out1 = o Wo^T + latents
-        d1T, d1_cd = ops.transpose(dout1, cd, want_same=True)
+        d1_cd = dout1 if dout1.dtype == cd else ops.cast(dout1, cd)
+        dWo = wgrad_side(d1_cd, o2, Wo)
         dO = ops.gemm_nt(d1_cd, shadows.wt(Wo, cd))
-        dWo = _wgrad(d1T, ops.transpose(o2, cd), param=Wo)
         kv3 = kv.view(G, nk, 2 * inner)
         dq, dkv = ops.attn_bwd(q.view(G, n2, inner), kv3[..., :inner], kv3[..., inner:], o2.view(G, n2, inner),
                                dO.view(G, n2, inner), lse, heads, None, 1, MASK_NONE, scale)
         dq2, dkv2 = dq.view(G * n2, inner), dkv.view(G * nk, 2 * inner)
-        dWq = _wgrad(ops.transpose(dq2, cd), ops.transpose(ln, cd), param=Wq)
-        dWkv = _wgrad(ops.transpose(dkv2, cd), ops.transpose(kv_in, cd), param=Wkv)
+        dWq = wgrad_side(dq2, ln, Wq)
+        dWkv = wgrad_side(dkv2, kv_in, Wkv, fork=False)
         dkv_in = ops.gemm_nt(dkv2, shadows.wt(Wkv, cd))                            # [G*nk, D] grads of [xn ; ln]
         # d(ln) = dq Wq (through to_q) + the latent rows of dkv_in (through to_kv)
         dln = ops.gemm_nt(dq2, shadows.wt(Wq, cd))
@@ -928,6 +961,9 @@ class PerceiverBlockFn(torch.autograd.Function):
                                           need_dx=need_dx)
         if need_dx:
             dx = dxm.view(G, n1, D)
+        side.join()
+        for prm in sunk:             # on THIS stream, after the join: the reducer orders its collective behind every writer
+            sink.ready(prm)
 
         def pg(g, p):
             if g is None:  # already delivered through the grad sink
