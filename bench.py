@@ -151,17 +151,32 @@ def run_c5(args, device, rank, world, use_dist):
     loss = None
     for _ in range(args.warmup):
         loss = step()
+    # roofline object of this config: the dominant hand-written kernel of the C5 step is the K-major GEMM; the launches of
+    # the MLP up-projection's weight gradient dW[16384, 4096] = dy^T x over the B*S token rows are timed with events on the launch stream
+    from otter_amd import ops as _ops
+
+    rM, rN, rK = text["intermediate_size"], text["hidden_size"], B * S
+    _ops.prof_arm_gemm(rM, rN, rK, max_events=max(64, args.steps * text["num_hidden_layers"] + 8))
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
     elapsed = time.perf_counter() - t0
+    n_launch, gemm_ms, _, _ = _ops.prof_collect_split()
+    _ops.prof_disarm()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     if rank == 0:
+        roof = None
+        if n_launch > 0:
+            avg_s = gemm_ms / n_launch / 1e3
+            ach = 2.0 * rM * rN * rK / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_bf16_t4_kernel, both operands K-major (weight gradient dy^T x) M=%d N=%d K=%d" % (rM, rN, rK),
+                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
         n_par = sum(p.numel() for p in params)
         flops = 6.0 * n_par * B * S + 12.0 * text["num_hidden_layers"] * B * S * S * 4096 * 0.5   # dense 6ND + causal attention fwd+bwd
         print(json.dumps({
@@ -174,6 +189,8 @@ def run_c5(args, device, rank, world, use_dist):
                        "every parameter trainable (%.2f B), bf16 autocast, fp32 masters" % (B, S, text_len, n_par / 1e9),
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
             "loss": round(float(loss), 4),
+            "roofline": roof,
+            "cpu_baseline": None,     # (reported on the BASELINE metric's line only -- config c2; the C5 oracle is a third-party class, tests/test_gpu_modules.py)
             "model_tflops_per_s": round(flops * args.steps / elapsed / 1e12, 1),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "reserved_mem_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1),

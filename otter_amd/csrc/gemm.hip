@@ -3609,6 +3609,163 @@ __global__ __launch_bounds__(256) void gemm_bf16_s4_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// bf16 small-grid kernel, HALF-HEIGHT tiles (variant 30, round 4): the ring kernel above on a 64 x 128 tile (4 waves of 32 x 64),
+// BK = 64 stages of 24 KB in the same 4-deep LDS-DMA ring.  Why: the ring kernel is bound by BYTES IN FLIGHT per CU (three stages of
+// prefetch against ~1.5-2 us of latency = ~62 GB/s per CU whatever the tile does with them), and the skinny products of the fusion modules
+// (4096 x 512 x 4096 in some order; the resampler's 512-row FFN) are only 32-128 tiles of 128 x 128: 128 or fewer of the 256 CUs stream at
+// all.  Half-height tiles double the workgroups (to_q / dWo / dWq: 256) -- 1.5 x the L2 -> LDS bytes in total, on twice the CUs.
+// Same LDS image, swizzle, fragment addresses and accumulation order per element as variant 25 (bit-identical results).
+// ------------------------------------------------------------------------------------------------------------
+template <int EPI, bool CBF16>
+__device__ __forceinline__ float tail_wave1_full(const GemmArgs& g, float s, const f32x16_t (&acc)[1][2], float* __restrict__ blk1, int64_t m_wave,
+                                                 int64_t n_wave, int lane) {
+    using T = TailShape<CBF16>;
+    const void* ip; int64_t ild; int idt;
+    const bool has_in = tail_input<EPI>(g, ip, ild, idt);
+    float part = 0.f;
+    park_block(blk1, acc[0][0], lane, 0);
+    park_block(blk1, acc[0][1], lane, 32);
+    __builtin_amdgcn_wave_barrier();
+    auto run = [&](auto inbf) {
+        constexpr bool INBF16 = decltype(inbf)::value;
+        uint4 r0[T::NIT][2];
+        if (has_in) tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave, lane, r0);
+        part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk1, m_wave, n_wave, lane, r0, has_in);
+    };
+    if (EPI == OTTER_EPI_GELU || idt == OTTER_BF16) run(std::true_type{});
+    else run(std::false_type{});
+    __builtin_amdgcn_wave_barrier();
+    return part;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_s4h_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 128, NT = 256;
+    constexpr int STAGE = (BM + BN) * 128;  // 24 KB: [64 A rows ; 128 B rows] x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
+    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
+    const int nk = (int)(g.K >> 6);  // stages (host guarantees nk % 4 == 0, nk >= 4)
+    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
+    // fragment read bases per k-step: A row = wm*32 + (lane&31), B row = wn*64 + i*32 + (lane&31); slot (2*ks + (lane>>5)) ^ ((row>>1)&7)
+    const int swz = ((lane & 31) >> 1) & 7;
+    int ra[4], rb[4], ra_hi[4], rb_hi[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int slot = (2 * ks + (lane >> 5)) ^ swz;
+        ra[ks] = (wm * 32 + (lane & 31)) * 128 + (slot << 4);
+        rb[ks] = BM * 128 + (wn * 64 + (lane & 31)) * 128 + (slot << 4);
+        ra_hi[ks] = ra[ks] + 2 * STAGE;
+        rb_hi[ks] = rb[ks] + 2 * STAGE;
+        asm volatile("" : "+v"(ra_hi[ks]), "+v"(rb_hi[ks]));
+    }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define LDF(dst, base, S_, KS, I)                                                                                          \
+    dst = *reinterpret_cast<const bf16x8_t*>(smem + ((S_) < 2 ? base[KS] + (S_) * STAGE : base##_hi[KS] + ((S_) - 2) * STAGE) + (I) * 4096)
+
+    const int ntiles = g.gm * g.gn;
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+        int tile_m, tile_n;
+        tile_of_block(g, vb, tile_m, tile_n);
+        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+        uint32_t oa[2], ob[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+            const int slot = phys ^ ((row >> 1) & 7);
+            if (i < 2) {
+                int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
+                oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
+            }
+            int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
+            ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
+        }
+        // piece p (0..1 = A, 2..5 = B) of the stage holding K columns [step*64, +64) into ring slot S_
+        auto dma = [&](int S_, int step, int p) {
+            if (p < 2) {
+                const int wbase = S_ * STAGE + (p * NT + wave * 64) * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p], step * 128, 0, 0);
+            } else {
+                const int wbase = S_ * STAGE + BM * 128 + ((p - 2) * NT + wave * 64) * 16;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p - 2], step * 128, 0, 0);
+            }
+        };
+        // ---- prologue: stages 0..2 in flight, 0 and 1 readable ----
+#pragma unroll
+        for (int st = 0; st < 3; ++st)
+#pragma unroll
+            for (int p = 0; p < 6; ++p) dma(st, st, p);
+        f32x16_t acc[1][2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][ni][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8_t fm[4][1], fn[4][2];  // [k-step][32-row block]
+        LDF(fn[0][0], rb, 0, 0, 0);
+        LDF(fm[0][0], ra, 0, 0, 0);
+        LDF(fn[0][1], rb, 0, 0, 1);
+#define MMA(KS, MI, NI) acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0)
+// one K-tile = 4 k-steps x 2 MFMAs; every slot requests fragments of the NEXT k-step (k-step 0 of the next stage during the last one),
+// the six DMA pieces of stage s+3 ride on the first six slots
+#define KSTEPH(S, STEPV, DMA, NEXT, VMW)                                                                                                   \
+    do {                                                                                                                                   \
+        constexpr int SN = ((S) + 1) & 3, SD = ((S) + 3) & 3;                                                                              \
+        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, S, 1, 0); SB(); LDF(fm[1][0], ra, S, 1, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 0); SB();      \
+        MMA(0, 0, 1); SB(); LDF(fn[1][1], rb, S, 1, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 1); SB();                                      \
+        MMA(1, 0, 0); SB(); LDF(fn[2][0], rb, S, 2, 0); SB(); LDF(fm[2][0], ra, S, 2, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 2); SB();      \
+        MMA(1, 0, 1); SB(); LDF(fn[2][1], rb, S, 2, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 3); SB();                                      \
+        MMA(2, 0, 0); SB(); LDF(fn[3][0], rb, S, 3, 0); SB(); LDF(fm[3][0], ra, S, 3, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 4); SB();      \
+        MMA(2, 0, 1); SB(); LDF(fn[3][1], rb, S, 3, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 5); SB();                                      \
+        MMA(3, 0, 0); SB(); if (NEXT) { LDF(fn[0][0], rb, SN, 0, 0); LDF(fm[0][0], ra, SN, 0, 0); } SB();                                  \
+        MMA(3, 0, 1); SB(); if (NEXT) { LDF(fn[0][1], rb, SN, 0, 1); } SB();                                                              \
+        asm volatile("s_waitcnt vmcnt(" #VMW ")" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                        \
+    } while (0)
+        int st = 0;
+        for (; st + 4 < nk; st += 4) {   // full trips: every step issues its stage st+3
+            KSTEPH(0, st, true, true, 6);
+            KSTEPH(1, st + 1, true, true, 6);
+            KSTEPH(2, st + 2, true, true, 6);
+            KSTEPH(3, st + 3, true, true, 6);
+        }
+        KSTEPH(0, st, true, true, 6);      // last trip: stage nk-1 is issued by its first step, then the queue drains
+        KSTEPH(1, st + 1, false, true, 0);
+        KSTEPH(2, st + 2, false, true, 0);
+        KSTEPH(3, st + 3, false, false, 0);
+#undef KSTEPH
+#undef MMA
+
+        // ---- epilogue: the ring is free (every DMA retired, every wave past the last barrier, every fragment read consumed) ----
+        float part = 0.f;
+        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (g.cdt == OTTER_F32 || g.wide);
+        float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+        if (full) {
+            if (g.cdt == OTTER_BF16) part = tail_wave1_full<EPI, true>(g, sgate, acc, blk, m0 + wm * 32, n0 + wn * 64, lane);
+            else part = tail_wave1_full<EPI, false>(g, sgate, acc, blk, m0 + wm * 32, n0 + wn * 64, lane);
+        } else {
+            park_block(blk, acc[0][0], lane, 0);
+            park_block(blk, acc[0][1], lane, 32);
+            __builtin_amdgcn_wave_barrier();
+            part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 32, n0 + wn * 64, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+        __syncthreads();  // the next tile's prologue DMA overwrites the stripes
+    }
+#undef LDF
+#undef SB
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // exact-f32 MFMA kernel (parity mode): 64x64x32 tile, 4 waves (2x2), one 32x32 accumulator block per wave
 // ------------------------------------------------------------------------------------------------------------
 template <int EPI>
@@ -3702,7 +3859,7 @@ int g_variant = 0;
 int g_debug = 0;
 int g_order = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
-enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_S4 = 25, CFG_T4 = 26, CFG_T4B = 27, CFG_T4C = 28, CFG_T4M = 29, CFG_F32 = 100 };
+enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_S4 = 25, CFG_T4 = 26, CFG_T4B = 27, CFG_T4C = 28, CFG_T4M = 29, CFG_S4H = 30, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
 int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
@@ -3721,7 +3878,7 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
     const bool ph = v == CFG_PH || v == CFG_PHC || v == CFG_PHB || v == CFG_PHCB || v == CFG_PHRB || v == CFG_PHLB || v == CFG_PHIB || v == CFG_PH2B || v == CFG_PHDB;
     if (ph && (K % 64 != 0 || wide)) v = (K % 64 == 0) ? CFG_256_GLDS : CFG_256;
     if ((v == CFG_Q4 || v == CFG_R4 || v == CFG_R4B || v == CFG_R4C || v == CFG_R4P || v == CFG_R4M || v == CFG_R4N || v == CFG_T4 || v == CFG_T4B || v == CFG_T4C || v == CFG_T4M) && (K % 128 != 0 || wide)) v = (K % 64 == 0 && !wide) ? CFG_PHLB : ((K % 64 == 0) ? CFG_256_GLDS : CFG_256);
-    if (v == CFG_S4 && (K % 256 != 0 || wide)) v = CFG_128;
+    if ((v == CFG_S4 || v == CFG_S4H) && (K % 256 != 0 || wide)) v = CFG_128;
     if (v == CFG_MS5B && wide) v = CFG_MS5;
     if (v == CFG_256_GLDS && (K % 64 != 0)) v = CFG_256;
     return v;
@@ -3729,6 +3886,7 @@ int pick_cfg(int64_t M, int64_t N, int64_t K, int ab_dtype, bool wide = false) {
 void cfg_tiles(int cfg, int& bm, int& bn) {
     if (cfg == CFG_F32) { bm = 64; bn = 64; }
     else if (cfg == CFG_128 || cfg == CFG_S4) { bm = 128; bn = 128; }
+    else if (cfg == CFG_S4H) { bm = 64; bn = 128; }
     else { bm = 256; bn = 256; }
 }
 
@@ -3901,6 +4059,14 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
 #undef LAUNCH_T4
         return OTTER_OK;
     }
+    if (cfg == CFG_S4H) {
+        static bool once = false;
+        const int smem = 4 * 24576;  // the ring; the tail's parking buffers (4 waves x 1 stripe) alias it
+        if (!once) { int rc = set_smem(gemm_bf16_s4h_kernel<EPI>, smem); if (rc) return rc; once = true; }
+        unsigned pg = grid.x < persistent_cus() ? grid.x : persistent_cus();
+        hipLaunchKernelGGL((gemm_bf16_s4h_kernel<EPI>), dim3(pg), dim3(256), smem, st, g);
+        return OTTER_OK;
+    }
     if (cfg == CFG_S4) {
         static bool once = false;
         const int smem = 4 * 32768;  // the ring; the tail's parking buffers (4 waves x 2 stripes = 69632 B) alias it
@@ -3960,18 +4126,18 @@ int otter_gemm_set_persistent(int on) {
 }
 
 int otter_gemm_variant_available(int variant) {
-    if (variant < 0 || variant > 29 || variant == 24) return 0;
+    if (variant < 0 || variant > 30 || variant == 24) return 0;
 #ifdef OTTER_EXPERIMENTAL
     return 1;
 #else
     // product build: auto (0), the generic 128^2 / 256^2 kernels (1-3), the phased fallback for K % 128 != 0 (13), the small-grid ring
     // (25) and the default (26); every other schedule is compiled into the tools-only experimental library
-    return variant <= 3 || variant == CFG_PHLB || variant == CFG_S4 || variant == CFG_T4;
+    return variant <= 3 || variant == CFG_PHLB || variant == CFG_S4 || variant == CFG_T4 || variant == CFG_S4H;
 #endif
 }
 
 int otter_gemm_set_variant(int variant) {
-    if (variant < 0 || variant > 29) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
+    if (variant < 0 || variant > 30) OTTER_FAIL(OTTER_ERR_ARG, "gemm variant %d", variant);
     if (!otter_gemm_variant_available(variant))
         OTTER_FAIL(OTTER_ERR_UNSUPPORTED, "gemm variant %d is in the experimental build only (python -m otter_amd.build --experimental)", variant);
     g_variant = variant;
@@ -4028,6 +4194,12 @@ int otter_gemm(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t 
     return gemm_impl(A, lda, a_kmajor ? 1 : 0, B, ldb, b_kmajor ? 1 : 0, C, ldc, M, N, K, ab_dtype, c_dtype, epi, stream);
 }
 
+static bool s4h_off() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OTTER_NO_S4H"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor, void* C, int64_t ldc, int64_t M, int64_t N,
                      int64_t K, int ab_dtype, int c_dtype, const otter_epilogue_args* epi, void* stream) {
     OTTER_REQUIRE(A && B && C && epi, "gemm: null pointer");
@@ -4068,7 +4240,13 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
     const int64_t esz = ab_dtype == OTTER_BF16 ? 2 : 4;
     const bool kmaj = a_kmajor || b_kmajor;
     const bool wide = !kmaj && (((M - 1) * lda + K) * esz >= (int64_t(1) << 32) || ((N - 1) * ldb + K) * esz >= (int64_t(1) << 32));
-    const int cfg = kmaj ? CFG_T4 : pick_cfg(M, N, K, ab_dtype, wide);
+    int cfg = kmaj ? CFG_T4 : pick_cfg(M, N, K, ab_dtype, wide);
+    // round 4: few 128 x 128 tiles of the ring kernel -> half-height tiles (variant 30), so that the skinny products (128 tiles or fewer on
+    // 256 CUs) stream on twice the CUs.  Not for a launch that writes per-block gate partials (their count follows otter_gemm_num_partials).
+    // OTTER_NO_S4H=1 (read once): A/B switch.
+    if (cfg == CFG_S4 && g_variant == 0 && !s4h_off() && cdiv64(M, 128) * cdiv64(N, 128) <= 160 && !(g.kind == OTTER_EPI_GATE_BWD && g.partial))
+        cfg = CFG_S4H;
+    if (cfg == CFG_S4H && g.kind == OTTER_EPI_GATE_BWD && g.partial) cfg = CFG_S4;   // (a forced variant 30)
     g.ta = a_kmajor; g.tb = b_kmajor;
     int bm, bn;
     cfg_tiles(cfg, bm, bn);

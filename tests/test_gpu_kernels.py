@@ -237,7 +237,7 @@ def test_llama_ops_golden(ops):
 # The product library carries the schedules pick_cfg can choose (1-3, 13, 25, 26); the kernel generations that led to them (rounds
 # 1-2) are compiled into the tools-only experimental library and are tested only when the suite is pointed at it
 # (OTTER_LIB_PATH=otter_amd/lib/libotter_hip_experimental.so python -m pytest tests/test_gpu_kernels.py -m gpu -k gemm).
-LIVE_VARIANTS = [1, 2, 3, 13, 25, 26]
+LIVE_VARIANTS = [1, 2, 3, 13, 25, 26, 30]
 _EXPERIMENTAL = os.environ.get("OTTER_LIB_PATH", "").endswith("experimental.so")
 
 
@@ -248,7 +248,7 @@ def variants(*cands):
 GEMM_SHAPES = [(48, 128, 48), (200, 136, 328), (257, 512, 64), (64, 384, 1024), (520, 264, 200), (300, 520, 256), (513, 260, 128)]
 
 
-@pytest.mark.parametrize("variant", variants(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26))
+@pytest.mark.parametrize("variant", variants(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26, 30))
 @pytest.mark.parametrize("M,N,Kd", GEMM_SHAPES)
 def test_gemm_bf16_store(ops, variant, M, N, Kd):
     ops.set_gemm_variant(variant)
@@ -276,7 +276,7 @@ def test_gemm_f32_store(ops, M, N, Kd):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-@pytest.mark.parametrize("variant", variants(1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26))
+@pytest.mark.parametrize("variant", variants(1, 2, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26, 30))
 def test_gemm_epilogues(ops, dt, variant):
     from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
 
@@ -327,7 +327,7 @@ def test_gemm_epilogues(ops, dt, variant):
         ops.set_gemm_variant(0)
 
 
-@pytest.mark.parametrize("variant", variants(17, 18, 19, 20, 21, 22, 23, 25, 26))
+@pytest.mark.parametrize("variant", variants(17, 18, 19, 20, 21, 22, 23, 25, 26, 30))
 @pytest.mark.parametrize("out_dt", ["bf16", "f32"])
 def test_gemm_full_tile_fast_tail(ops, variant, out_dt):
     """The one-wave-per-SIMD kernels take an unrolled, double-buffered tail on full in-bounds tiles: every epilogue kind and
@@ -495,6 +495,49 @@ def test_gemm_bench_shapes(ops, M, N, Kd, kind, out_dt, layout):
         assert abs(dg - want) < 1e-5 * scale + 1e-3
 
 
+@pytest.mark.parametrize("M,N,Kd", [(4096, 512, 4096), (512, 4096, 4096), (512, 1024, 4096), (520, 384, 1024), (72, 128, 512)])
+def test_gemm_half_height_ring_equals_ring(ops, M, N, Kd):
+    """Round 4, variant 30 (64 x 128 tiles of the small-grid ring kernel: the skinny projections of the gated block / the resampler's
+    512-row products on twice the workgroups).  Same fragments and per-element accumulation order as variant 25 -> bit-identical results
+    for every epilogue kind and both output dtypes, ragged M / N edges included; fp64 product on sampled rows; and the default dispatch
+    (variant 0) takes it exactly for the few-tile shapes."""
+    from otter_amd._capi import EPI_GATE_BWD, EPI_GELU, EPI_SCALE_RES, EPI_STORE
+
+    r = rng(M + N + Kd)
+    A = to_dev(bf16_round(r.standard_normal((M, Kd)) * 0.3), torch.bfloat16)
+    B = to_dev(bf16_round(r.standard_normal((N, Kd)) * 0.3), torch.bfloat16)
+    R = to_dev(r.standard_normal((M, N)).astype(np.float32))
+    aux = to_dev(bf16_round(r.standard_normal((M, N))), torch.bfloat16)
+    gate = to_dev(np.array([0.7], np.float32))
+
+    def run(v):
+        ops.set_gemm_variant(v)
+        out = {}
+        for odt, tag in ((torch.bfloat16, "b"), (torch.float32, "f")):
+            out["store" + tag] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_STORE, gate=gate)
+            C2 = torch.empty((M, N), dtype=odt, device=DEV)
+            out["gelu" + tag] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_GELU, C2=C2)
+            out["pre" + tag] = C2
+            out["res" + tag] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_SCALE_RES, gate=gate, R=R)
+            out["gbwd" + tag] = ops.gemm_nt(A, B, out_dtype=odt, kind=EPI_GATE_BWD, gate=gate, aux=aux, aux_gelu=True)    # (no partials: stays on 30)
+        acc = out["storef"].clone()
+        ops.gemm_nt(A, B, out=acc, kind=EPI_STORE, accumulate=True)
+        out["accum"] = acc
+        return out
+
+    try:
+        half, ring, auto = run(30), run(25), run(0)
+    finally:
+        ops.set_gemm_variant(0)
+    for k in ring:
+        assert torch.equal(half[k], ring[k]), k
+        assert torch.equal(auto[k], ring[k]), k
+    rows = np.unique(np.concatenate([[0, 63, 64, M - 1], r.integers(0, M, 40)]))
+    ref = host(A)[rows].astype(np.float64) @ host(B).astype(np.float64).T
+    assert relmax(host(half["storef"])[rows], ref * np.tanh(0.7)) < 2e-4
+    assert relmax(host(half["preb"])[rows], ref) < 1e-2
+
+
 KMAJOR_CASES = [
     # (M, N, K, a_kmajor, b_kmajor, extra leading-dimension padding): >= 192 tiles of 256 x 256, K % 128 == 0
     (4096, 4096, 256, True, True, 0),       # wgrad form, square grid
@@ -596,7 +639,7 @@ def test_gemm_big_variants_agree(ops):
     B = to_dev(r.standard_normal((N, Kd)), torch.bfloat16)
     ref = host(A).astype(np.float64) @ host(B).astype(np.float64).T
     outs = []
-    for v in variants(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26):
+    for v in variants(1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 25, 26, 30):
         ops.set_gemm_variant(v)
         outs.append(ops.gemm_nt(A, B, out_dtype=torch.float32))
     ops.set_gemm_variant(0)
