@@ -662,6 +662,197 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// forward, version 3 (round 4, flash variant 6): SIXTEEN queries per wave on v_mfma_f32_16x16x32_bf16, eight waves per workgroup.
+// Why: the counters of version 2 (profiles/r04_pmc_flash.json) show a latency-bound loop -- 41 % of the wave cycles are waits, 17 % issue
+// VALU, the matrix pipe is 15 % busy -- with two waves per SIMD (202 registers each).  A wave that owns 16 queries instead of 32 needs
+// S^T 16 + O^T 32 + Q 16 registers: <= 128 in all, FOUR waves per SIMD, so twice as many dependent chains (MFMA accumulate, max / shuffle /
+// exp) are in flight per SIMD.  Same 64 KB K0 | K1 | V0 | V1 LDS tiles (64 keys), same LDS-DMA double buffering, same LPT block order.
+// Orientation (A: lane l = row l&15, k = 8(l>>4)..+7;  B: lane l = column l&15, same k;  C: lane l = column l&15, rows 4(l>>4)+0..3):
+//   S^T[key][query] = K Q^T per 16-key block: lane (g = l>>4, j = l&15) holds keys 4g..4g+3 of each of the tile's four blocks for query j
+//   (row statistics: two cross-lane exchanges, xor 16 and 32); the P^T registers of blocks 2s, 2s+1 are, as they stand, the B operand of
+//   O^T[d][query] += V^T P^T over the 32 keys {16(2s)+4g+r, 16(2s+1)+4g+r}; the matching A operand V^T comes out of the row-major V tile by
+//   two ds_read_b64_tr_b16 (rows 16(2s)+4g.., 16(2s+1)+4g.. of the 16-column d block).
+// Swizzles (on the DMA source offsets): K as in version 2 (16-B slot ^= row & 15: the 16 lanes of a ds_read_b128 service group hit 16
+// distinct slots); V: 32-B unit ^= row & 7 (the 8 rows one pass of the transpose read touches hit 8 distinct units).
+// ------------------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool LPT>
+__global__ __launch_bounds__(512, 4) void flash_fwd3_kernel(FlashArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqb = (a.Sq + 127) >> 7;
+    const LptIdx li = lpt_decode((int)blockIdx.x, nqb, a.lpt_group);
+    const int b = LPT ? li.bh / a.H : blockIdx.z, hd = LPT ? li.bh % a.H : blockIdx.y;
+    const int q0 = (LPT ? nqb - 1 - li.rank : (int)blockIdx.x) * 128;
+    const int qi = q0 + wave * 16 + j;
+    const int off = a.Sk - a.Sq;
+    const bf16_t* qp = a.q + b * a.qs.b + hd * a.qs.h + (int64_t)(qi < a.Sq ? qi : a.Sq - 1) * a.qs.s;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 32 * ks + 8 * g);
+    const bf16_t* kb = a.k + b * a.ks.b + hd * a.ks.h;
+    const bf16_t* vb = a.v + b * a.vs.b + hd * a.vs.h;
+    const uint8_t* kv = a.kvalid ? a.kvalid + (int64_t)b * a.Sk : nullptr;
+    const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd] * LOG2E : 0.f;
+    int nkt = (a.Sk + 63) >> 6;
+    if (a.causal) {
+        const int qmax = (q0 + 127 < a.Sq ? q0 + 127 : a.Sq - 1) + off;
+        const int lim = qmax < 0 ? 0 : (qmax >> 6) + 1;
+        nkt = nkt < lim ? nkt : lim;
+    }
+    const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
+    const u32x4_t rk = make_rsrc4(kb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u)));
+    const u32x4_t rv = make_rsrc4(vb, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u)));
+    // DMA: a tile is 16 pieces of 1 KB (4 rows x 256 B) per operand; wave w issues pieces 2w, 2w+1 of K and of V
+    uint32_t vk[2], vv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rl = 4 * (wave * 2 + i) + (lane >> 4), p = lane & 15;
+        const int sk = p ^ (rl & 15), sv = (((p >> 1) ^ (rl & 7)) << 1) | (p & 1);   // source slot that lands in LDS slot p
+        vk[i] = (uint32_t)rl * krow + (uint32_t)(sk << 4);
+        vv[i] = (uint32_t)rl * vrow + (uint32_t)(sv << 4);
+    }
+    auto dma_tile = [&](char* kdst, char* vdst, uint32_t ksoff, uint32_t vsoff) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dma16_asm(rk, kdst + (wave * 2 + i) * 1024, vk[i], ksoff);
+            dma16_asm(rv, vdst + (wave * 2 + i) * 1024, vv[i], vsoff);
+        }
+    };
+    // read side.  K fragment (key block kb, k-step ks): row 16 kb + j, logical slot 4 ks + g -> byte (kfo ^ (ks << 6)) + 4096 kb.
+    // V transpose read (32-key step s, d block db): lane i = j of group g supplies row 32 s + 4 g + (j >> 2) (+ 16), unit db ^ (row & 7)
+    const int kfo = j * 256 + ((g ^ j) << 4);
+    const int vto = (4 * g + (j >> 2)) * 256 + ((4 * (g & 1) + (j >> 2)) << 5) + 8 * (j & 3);
+    float m = -INFINITY, lsum = 0.f;
+    f32x4_t o[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db) o[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned long long* const kmask = reinterpret_cast<unsigned long long*>(smem + 65536);
+    const bool kmask_lds = kv != nullptr && nkt <= KMASK_TILES;
+    if (kmask_lds) {
+        for (int t = wave; t < nkt; t += 8) {
+            const int jj = t * 64 + lane;
+            const unsigned long long mk = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0);
+            if (lane == 0) kmask[t] = mk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // published by the first barrier of the loop
+    }
+    if (nkt > 0) dma_tile(smem, smem + 32768, 0u, 0u);
+    __builtin_amdgcn_s_waitcnt(0x0F70);    // every load hipcc knows about is retired here (see version 2)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave; every wave is done with tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt)
+            dma_tile(smem + (cur ^ 1) * 16384, smem + 32768 + (cur ^ 1) * 16384, (uint32_t)(kt + 1) * 64u * krow, (uint32_t)(kt + 1) * 64u * vrow);
+        const int k0 = kt * 64;
+        const int wq0 = q0 + wave * 16 + off;  // first query of the wave, in key coordinates
+        if (a.causal && k0 > wq0 + 15) continue;  // whole tile above this wave's diagonal
+        const char* Kc = smem + cur * 16384;
+        const char* Vc = smem + 32768 + cur * 16384;
+        f32x4_t s[4];
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk) {
+            s[kbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s[kbk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(Kc + kbk * 4096 + (kfo ^ (ks << 6))), qf[ks], s[kbk], 0, 0, 0);
+        }
+        const float base = sl2 * (float)(k0 + 4 * g - (a.Sk - 1));
+        float mx = -INFINITY;
+        const bool interior = kv == nullptr && k0 + 63 < a.Sk && (!a.causal || k0 + 63 <= wq0);
+        if (interior) {
+#pragma unroll
+            for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = fmaf(s[kbk][r], sc2, fmaf(sl2, (float)(16 * kbk + r), base));
+                    s[kbk][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+        } else {
+            // visibility of the lane's 16 keys (16 kbk + 4 g + r) as one word: causal / sequence-end limit ANDed with the key-padding bits
+            const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
+            const int limh = (a.causal && rel < kend ? rel : kend) - 4 * g;
+            unsigned long long vmh = ~0ull;
+            if (kmask_lds) {
+                vmh = kmask[kt] >> (4 * g);
+            } else if (kv) {
+                const int jj = k0 + lane;
+                vmh = __ballot(jj < a.Sk && kv[jj < a.Sk ? jj : 0] != 0) >> (4 * g);
+            }
+            const unsigned long long okm = limh < 0 ? 0ull : (limh >= 63 ? vmh : vmh & ((2ull << limh) - 1ull));
+            const unsigned okm_lo = (unsigned)okm, okm_hi = (unsigned)(okm >> 32);
+#pragma unroll
+            for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cidx = 16 * kbk + r;
+                    float x = fmaf(s[kbk][r], sc2, fmaf(sl2, (float)cidx, base));
+                    const unsigned mk = (unsigned)__builtin_amdgcn_sbfe((int)(cidx < 32 ? okm_lo : okm_hi), cidx & 31, 1);
+                    x = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, x) & mk) | (~mk & 0xFF800000u));
+                    s[kbk][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // lazy rescale: only when some row's maximum grew by more than 8 (log2 units) -- wave-uniform decision
+        if (__ballot(mx > m + 8.0f) != 0ull) {
+            const float mnew = fmaxf(m, mx);
+            const float muse = mnew == -INFINITY ? 0.f : mnew;
+            const float alpha = __builtin_amdgcn_exp2f(m - muse);
+            m = mnew;
+            lsum *= alpha;
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+        }
+        const float muse = m == -INFINITY ? 0.f : m;
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kbk][r] - muse);
+                s[kbk][r] = p;
+                lsum += p;
+            }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8_t pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pf[r] = (__bf16)s[2 * st][r]; pf[4 + r] = (__bf16)s[2 * st + 1][r]; }
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                const char* tp = Vc + st * 8192 + (vto ^ (db << 5));
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)tp);
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tp + 4096));
+                const s16x8_t vfr = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vfr), pf, o[db], 0, 0, 0);
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 16, 64);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    if (qi < a.Sq) {
+        bf16_t* rowp = a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            uint2 w;
+            w.x = pack2bf(o[db][0] * inv, o[db][1] * inv);
+            w.y = pack2bf(o[db][2] * inv, o[db][3] * inv);
+            *reinterpret_cast<uint2*>(rowp + 16 * db + 4 * g) = w;
+        }
+        if (g == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // delta[b,h,q] = sum_d dO . O   (16 lanes per row)
 // ------------------------------------------------------------------------------------------------------------
 template <int LPR>   // lanes per row: head_dim / 8
@@ -1653,7 +1844,7 @@ int set_smem(K kern, int bytes) {
 extern "C" {
 
 int otter_flash_set_variant(int v) {
-    OTTER_REQUIRE(v >= 0 && v <= 5, "flash variant %d (0 = default: LDS-DMA v2, LPT block order, delta inside the dQ kernel; 1 = register-staged v1; 2 = v2, plain grid; 3 = 2 + dK/dV at two workgroups per CU; 4 = 0 with the separate flash_delta launch (round-3 order); 5 = 0 + dK/dV at two workgroups per CU)", v);
+    OTTER_REQUIRE(v >= 0 && v <= 6, "flash variant %d (6 = forward version 3: 16 queries per wave, 16x16x32 MFMA, four waves per SIMD; 0 = default: LDS-DMA v2, LPT block order, delta inside the dQ kernel; 1 = register-staged v1; 2 = v2, plain grid; 3 = 2 + dK/dV at two workgroups per CU; 4 = 0 with the separate flash_delta launch (round-3 order); 5 = 0 + dK/dV at two workgroups per CU)", v);
     g_flash_variant = v;
     return OTTER_OK;
 }
@@ -1684,6 +1875,17 @@ int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream) {
             if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd2_kernel<true, true, false>), g1, dim3(256), smem, (hipStream_t)stream, a);
             else hipLaunchKernelGGL((flash_fwd2_kernel<false, true, false>), g3, dim3(256), smem, (hipStream_t)stream, a);
         }
+    } else if (v2 && g_flash_variant == 6) {
+        const int smem = 65536 + KMASK_TILES * 8;
+        static bool once = false;
+        if (!once) {
+            rc = set_smem(flash_fwd3_kernel<false>, smem); if (rc) return rc;
+            rc = set_smem(flash_fwd3_kernel<true>, smem); if (rc) return rc;
+            once = true;
+        }
+        const unsigned nqb = (unsigned)((a.Sq + 127) / 128);
+        if (flash_lpt(a)) hipLaunchKernelGGL((flash_fwd3_kernel<true>), dim3(nqb * a.H * a.B), dim3(512), smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((flash_fwd3_kernel<false>), dim3(nqb, a.H, a.B), dim3(512), smem, (hipStream_t)stream, a);
     } else if (v2) {
 #ifdef OTTER_FLASH_TIMING
         const int smem = 65536 + KMASK_TILES * 8 + 1024;

@@ -54,7 +54,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("B,H,S,causal,alibi,lens", CASES)
 def test_flash_attention_fwd_bwd(ops, B, H, S, causal, alibi, lens, variant):
     from otter_amd.mpt import alibi_slopes
