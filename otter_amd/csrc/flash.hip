@@ -80,10 +80,34 @@ __device__ unsigned long long* g_flash_stamps = nullptr;
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                 \
         if (LPT && blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 96) reinterpret_cast<unsigned long long*>(smem + 65536 + 1024)[slot] = t_; \
     } while (0)
+// whole-launch picture: every workgroup of kernel KID (0 forward, 1 dQ, 2 dK/dV) records begin / end in the 100 MHz constant clock
+// (s_memrealtime: the same counter on every XCD) and where it ran (HW_ID, XCC_ID)
+__device__ unsigned long long* g_flash_blk = nullptr;
+#define BLK_LIN() ((int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z))
+#define BLK_BEGIN(KID)                                                                                            \
+    do {                                                                                                          \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+        if (g_flash_blk && threadIdx.x == 0 && BLK_LIN() < 4096) {                                                \
+            unsigned hw_, xc_;                                                                                    \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                     \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc_));                                    \
+            unsigned long long* r_ = g_flash_blk + ((KID) * 4096 + BLK_LIN()) * 4;                                \
+            r_[0] = t_; r_[2] = hw_; r_[3] = xc_;                                                                 \
+        }                                                                                                         \
+    } while (0)
+#define BLK_END(KID)                                                                                              \
+    do {                                                                                                          \
+        unsigned long long t_;                                                                                    \
+        asm volatile("s_waitcnt vmcnt(0)\n s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+        if (g_flash_blk && threadIdx.x == 0 && BLK_LIN() < 4096) g_flash_blk[((KID) * 4096 + BLK_LIN()) * 4 + 1] = t_; \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
 #define DSTAMP(slot) do {} while (0)
 #define FSTAMP(slot) do {} while (0)
+#define BLK_BEGIN(KID) do {} while (0)
+#define BLK_END(KID) do {} while (0)
 #endif
 
 __device__ __forceinline__ f32x16_t zero16() {
@@ -369,6 +393,7 @@ __device__ __forceinline__ void flash_dma_tile(u32x4_t rk, u32x4_t rv, char* kds
 // (C5 shape, forward / backward: 142 / 451 us one path, 153 / 650 two paths, 196 / 505 one workgroup per CU; zero-padded heads 205 / 694).
 template <bool LPT, bool PAIR = false, bool ALIBI = true>   // ALIBI = false (pair kernels only): no slopes, the bias arithmetic is compiled out
 __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
+    BLK_BEGIN(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -653,6 +678,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         store_dt(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s, o, inv, h2);
         if (h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
     }
+    BLK_END(0);
 #ifdef OTTER_FLASH_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     FSTAMP(91);
@@ -1138,6 +1164,7 @@ __device__ __forceinline__ bf16x8_t tr_pi_frag(const char* tile, int o1, int o2,
 
 template <bool LPT, bool PAIR = false, bool ALIBI = true>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
 __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
+    BLK_BEGIN(1);
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K0 | K1 | V0 | V1, 16 KB each
     const int tid = threadIdx.x, lane = tid & 63, h2 = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1347,10 +1374,12 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
         return;
     }
     if (qi < a.Sq) store_dt(a.dq + b * a.dqs.b + hd * a.dqs.h + (int64_t)qi * a.dqs.s, dq, a.scale, h2);
+    BLK_END(1);
 }
 
 template <int MINB, bool LPT, bool PAIR = false>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
 __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) {
+    BLK_BEGIN(2);
     // 3-stage ring, two query tiles in flight (a 32-row tile is only ~1k MFMA cycles of work, less than the DMA latency):
     // Q[3] | dO[3] (8 KB each) | lse2[3][64] | delta[3][64]
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1774,6 +1803,7 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         store_dt(a.dk + b * a.dks.b + hd * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, h2);
         store_dt(a.dv + b * a.dvs.b + hd * a.dvs.h + (int64_t)kj * a.dvs.s, dv, 1.0f, h2);
     }
+    BLK_END(2);
 #ifdef OTTER_FLASH_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DSTAMP(91);
@@ -2009,6 +2039,10 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
 #ifdef OTTER_FLASH_TIMING
 int otter_flash_set_stamps(void* dev_ptr) {  // diagnostics builds only; not part of include/otter_hip.h
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_flash_stamps), &dev_ptr, sizeof(void*));
+    return e == hipSuccess ? 0 : -1;
+}
+int otter_flash_set_block_stamps(void* dev_ptr) {  // [3][4096][4] u64: begin, end (10 ns ticks), HW_ID, XCC_ID per workgroup
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_flash_blk), &dev_ptr, sizeof(void*));
     return e == hipSuccess ? 0 : -1;
 }
 #endif
