@@ -363,11 +363,20 @@ __device__ __forceinline__ void dma4_asm(u32x4_t r, const char* lds, uint32_t vo
                  : "=&s"(keep) : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 #else
+// (diagnostics build: the stamp stores under `threadIdx.x == 0` make hipcc treat the ring-slot address of the persistent dK/dV kernel as
+//  divergent and hand a VGPR to the "s" operand; an explicit readfirstlane there only)
+#ifdef OTTER_FLASH_TIMING
+#define DMA_LDS_ADDR(P_) ((unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(P_)))
+#define DMA_SOFF(S_) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(S_)))
+#else
+#define DMA_LDS_ADDR(P_) lds_addr(P_)
+#define DMA_SOFF(S_) (S_)
+#endif
 __device__ __forceinline__ void dma16_asm(u32x4_t r, const char* lds, uint32_t voff, uint32_t soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(DMA_LDS_ADDR(lds)), "v"(voff), "s"(r), "s"(DMA_SOFF(soff)) : "memory");
 }
 __device__ __forceinline__ void dma4_asm(u32x4_t r, const char* lds, uint32_t voff, uint32_t soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds_addr(lds)), "v"(voff), "s"(r), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(DMA_LDS_ADDR(lds)), "v"(voff), "s"(r), "s"(DMA_SOFF(soff)) : "memory");
 }
 #endif
 
@@ -1377,7 +1386,45 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
     BLK_END(1);
 }
 
-template <int MINB, bool LPT, bool PAIR = false>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
+// PERS (round 4): ONE workgroup per (batch, head) walks ALL key blocks of that head (grid = B * H, one per CU at C2).  The launch picture
+// (tools/flash_launch_picture.py, profiles/r04_flash_launch_picture.txt) showed every workgroup of this kernel paying ~10 us of fixed cost
+// -- cold K / V fragment loads, pipeline fill, 32 sixteen-byte-per-row stores and their drain, the dispatch gap -- around 1.4 us per query
+// tile, four workgroups one after the other on each CU: 40 of 101 us.  Here the Q / dO ring simply keeps running across key blocks (the
+// tile after the last one of block r is the first one of block r+1), the next block's K / V rows are DMA-staged into wave-private LDS one
+// whole block ahead, and dK / dV leave through an LDS transpose as full 256-B rows.
+constexpr int DKV_STG = 52224;              // PERS: K | V of the NEXT key block, 2 x 8 KB per wave
+constexpr int DKV_TRN = DKV_STG + 65536;    // PERS: 8 KB per wave for the row-major dK / dV tile on its way out
+constexpr int DKV_PERS_SMEM = DKV_TRN + 32768;
+
+// dK / dV rows of one wave (32 keys x 128) from the S^T-orientation accumulators to global memory through LDS: lane (ql, h2) holds
+// d = 32 db + 8 g + 4 h2 + e of key ql; written as 8-B pieces into a 16-B-slot-swizzled row-major tile, read back as 16 B per lane,
+// four whole rows per store instruction
+template <bool PAIR>
+__device__ __forceinline__ void store_rows_lds(char* trn, bf16_t* base, int64_t row_stride, int row0, int nrows_valid, const f32x16_t (&acc)[4],
+                                               float mul0, float mul1, int lane, int64_t poff) {
+    const int ql = lane & 31, h2 = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const float mul = (PAIR && db >= 2) ? mul1 : mul0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
+            w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(trn + ql * 256 + (((4 * db + g) ^ (ql & 15)) << 4) + 8 * h2) = w;
+        }
+    }
+    const int p = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + (lane >> 4);
+        const uint4 w = *reinterpret_cast<const uint4*>(trn + row * 256 + ((p ^ (row & 15)) << 4));
+        if (row0 + row < nrows_valid)
+            *reinterpret_cast<uint4*>(base + (int64_t)(row0 + row) * row_stride + 8 * p + ((PAIR && p >= 8) ? poff : 0)) = w;
+    }
+}
+
+template <int MINB, bool LPT, bool PAIR = false, bool PERS = false>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
 __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) {
     BLK_BEGIN(2);
     // 3-stage ring, two query tiles in flight (a 32-row tile is only ~1k MFMA cycles of work, less than the DMA latency):
@@ -1388,11 +1435,12 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // LPT: 1-D grid walked key block by key block -- under the causal mask key block 0 has the most query tiles, so the longest blocks
     // are dispatched first and the launch ends on the short ones
-    const LptIdx li = lpt_decode((int)blockIdx.x, (a.Sk + 127) >> 7, a.lpt_group);
+    const int nkb = (a.Sk + 127) >> 7;
+    const LptIdx li = lpt_decode((int)blockIdx.x, nkb, a.lpt_group);
     const int HB = PAIR ? a.H >> 1 : a.H, hm = PAIR ? 2 : 1;
-    const int b = LPT ? li.bh / HB : blockIdx.z, hd = LPT ? li.bh % HB : blockIdx.y;
-    const int k0 = (LPT ? li.rank : (int)blockIdx.x) * 128;
-    const int kw = k0 + wave * 32, kj = kw + ql;
+    const int b = PERS ? (int)blockIdx.x / HB : (LPT ? li.bh / HB : (int)blockIdx.z), hd = PERS ? (int)blockIdx.x % HB : (LPT ? li.bh % HB : (int)blockIdx.y);
+    int k0 = PERS ? 0 : (LPT ? li.rank : (int)blockIdx.x) * 128;   // PERS: key block 0 first (the most query tiles under the causal mask)
+    int kw = k0 + wave * 32, kj = kw + ql;
     const int off = a.Sk - a.Sq;
     const int kc = kj < a.Sk ? kj : a.Sk - 1;
     const bf16_t* kp = a.k + b * a.ks.b + hd * hm * a.ks.h + (int64_t)kc * a.ks.s;
@@ -1406,20 +1454,36 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     }
     bool kok = kj < a.Sk;
     if (a.kvalid) kok = kok && a.kvalid[(int64_t)b * a.Sk + kc] != 0;
+    unsigned kvbits = 0xffffffffu;   // PERS: this lane's key-padding bit of every key block (<= 32 blocks), read once
+    if constexpr (PERS) {
+        if (a.kvalid) {
+            kvbits = 0u;
+            for (int r = 0; r < nkb; ++r) {
+                const int kk = r * 128 + wave * 32 + ql;
+                if (a.kvalid[(int64_t)b * a.Sk + (kk < a.Sk ? kk : a.Sk - 1)] != 0) kvbits |= 1u << r;
+            }
+        }
+    }
     const float sc2 = a.scale * LOG2E, sl2 = a.slopes ? a.slopes[hd * hm] * LOG2E : 0.f;
-    const float bias2 = sl2 * (float)(kj - (a.Sk - 1));
-    const float bias2B = PAIR && a.slopes ? a.slopes[hd * 2 + 1] * LOG2E * (float)(kj - (a.Sk - 1)) : 0.f;
+    const float sl2B = PAIR && a.slopes ? a.slopes[hd * 2 + 1] * LOG2E : 0.f;
+    // (__fmul_rn: a product the compiler may not contract into the `bias2 - lse` of the tile loop -- with -ffp-contract=fast it did so in
+    //  the per-block instantiations, where bias2 is loop-invariant, and not in PERS: last-bit differences between the two forms)
+    float bias2 = __fmul_rn(sl2, (float)(kj - (a.Sk - 1)));
+    float bias2B = __fmul_rn(sl2B, (float)(kj - (a.Sk - 1)));
     const bf16_t* qb = a.q + b * a.qs.b + hd * hm * a.qs.h;
     const bf16_t* dob = a.dout + b * a.dos.b + hd * hm * a.dos.h;
     const int64_t nrows = (int64_t)a.B * a.H * a.Sq;
     const float* dlb = a.delta + ((int64_t)b * a.H + hd * hm) * a.Sq;
     const float* lsb = dlb + nrows;
     const int nqt = (a.Sq + 31) >> 5;
-    int qt0 = 0;
-    if (a.causal) {
-        const int imin = k0 - off;
-        qt0 = imin > 0 ? (imin >> 5) : 0;
-    }
+    auto first_tile_of = [&](int kb0) {   // first query tile that sees any key of the 128-key block starting at kb0
+        const int imin = kb0 - off;
+        return a.causal && imin > 0 ? (imin >> 5) : 0;
+    };
+    int qt0 = first_tile_of(k0);
+    // PERS: first tile of the NEXT key block (the ring runs on into it); past the last block: tiles beyond Sq (the DMA reads zeros)
+    int qtn = PERS ? (nkb > 1 ? first_tile_of(128) : nqt + 2) : 0;
+    int rank = 0;
     const uint32_t qrow = (uint32_t)(a.qs.s * 2), dorow = (uint32_t)(a.dos.s * 2);
     const uint32_t qpb = PAIR ? (uint32_t)((a.qs.h - 64) * 2) : 0u, dpb = PAIR ? (uint32_t)((a.dos.h - 64) * 2) : 0u;
     const u32x4_t rq = make_rsrc4(qb, (uint32_t)((int)((uint32_t)(a.Sq - 1) * qrow + 256u + qpb)));
@@ -1438,6 +1502,26 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         vd[i] = (uint32_t)rl * dorow + (uint32_t)(sq << 4) + (sq >= 8 ? dpb : 0u);
     }
     char* const stat = smem + 49152;
+    // PERS: staging of the next key block's K / V rows (this wave's 32 keys, 2 x 8 DMA pieces of four 256-B rows), same slot swizzle as the
+    // Q / dO tiles so the fragments come out through the same `qfo ^ 32c` addresses
+    char* const stK = smem + DKV_STG + wave * 16384;
+    char* const stV = stK + 8192;
+    const uint32_t krow = (uint32_t)(a.ks.s * 2), vrow = (uint32_t)(a.vs.s * 2);
+    const uint32_t kpb = PAIR ? (uint32_t)((a.ks.h - 64) * 2) : 0u, vpb = PAIR ? (uint32_t)((a.vs.h - 64) * 2) : 0u;
+    u32x4_t rks = {0u, 0u, 0u, 0u}, rvs = {0u, 0u, 0u, 0u};
+    if constexpr (PERS) {
+        rks = make_rsrc4(a.k + b * a.ks.b + hd * hm * a.ks.h, (uint32_t)((int)((uint32_t)(a.Sk - 1) * krow + 256u + kpb)));
+        rvs = make_rsrc4(a.v + b * a.vs.b + hd * hm * a.vs.h, (uint32_t)((int)((uint32_t)(a.Sk - 1) * vrow + 256u + vpb)));
+    }
+    auto stage_kv = [&](int kw_next) {
+        const int r4 = lane >> 4, pp = lane & 15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int sq = pp ^ ((r4 << 2) | (i & 3));   // = p ^ pi16((4 i + r4) & 15)
+            dma16_asm(rks, stK + i * 1024, (uint32_t)r4 * krow + (uint32_t)(sq << 4) + (sq >= 8 ? kpb : 0u), (uint32_t)(kw_next + 4 * i) * krow);
+            dma16_asm(rvs, stV + i * 1024, (uint32_t)r4 * vrow + (uint32_t)(sq << 4) + (sq >= 8 ? vpb : 0u), (uint32_t)(kw_next + 4 * i) * vrow);
+        }
+    };
     auto issue = [&](int qt, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1455,6 +1539,9 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     f32x16_t dk[4], dv[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+    if constexpr (PERS) {
+        if (nkb > 1) stage_kv(kw + 128);   // older than every ring piece: the loop's counted waits cover it
+    }
     issue(qt0, 0);       // unconditional (see the loop): rows past Sq read as zeros
     issue(qt0 + 1, 1);
     // every load hipcc knows about (the register-resident fragments above) is retired HERE, through the builtin its scoreboard models:
@@ -1499,9 +1586,13 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
 #define MFMA_ACC(ACC_, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_))
 #define MFMA_ACC_MEM(ACC_, A_, B_) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC_) : "v"(A_), "v"(B_) : "memory")
     int cur = 0;
+    bool first = false;   // PERS: first tile of a key block other than block 0 (its successor tile was waited for at the switch)
+    for (;;) {
     for (int qt = qt0; qt < nqt; ++qt, cur = cur == 2 ? 0 : cur + 1) {
         DSTAMP(1 + 5 * (qt - qt0));
         const int i0 = qt * 32;
+        // tile after next: PERS runs on into the next key block's first tiles
+        const int qt2 = PERS ? (qt + 2 < nqt ? qt + 2 : qtn + (qt + 2 - nqt)) : qt + 2;
         // (no per-wave skip of tiles that precede the wave's keys: the branch makes hipcc shuttle the 128 accumulator
         //  registers between VGPRs and AGPRs on every iteration, which costs more than the <= 3 masked tiles it saves)
         const char* Qc = smem + cur * 8192;
@@ -1556,8 +1647,8 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
                             tQ[cc][1] = tr_pi_frag(Qc, to1, to2, 2 * e + 1, 16 * cc);
                         }
                     }
-                    if (e == 0) issue_piece(qt + 2, nb, c4);
-                    else if (c4 == 0 && wave == 0) { issue_piece(qt + 2, nb, 4); issue_piece(qt + 2, nb, 5); }
+                    if (e == 0) issue_piece(qt2, nb, c4);
+                    else if (c4 == 0 && wave == 0) { issue_piece(qt2, nb, 4); issue_piece(qt2, nb, 5); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s), "+v"(dp));
@@ -1618,7 +1709,8 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
                 }
                 const bf16x8_t pf1 = pack8(s, 8), dsf1 = pack8(dp, 8);
                 if (e == 1) {
-                    if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                    if (PERS && first) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); first = false; }
+                    else if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
@@ -1668,8 +1760,8 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
                     tQ[cc][db0 + 1] = tr_pi_frag(Qc, to1, to2, db0 + 1, 16 * cc);
                 }
             }
-            if (c < 4) issue_piece(qt + 2, nb, c);
-            else if (c == 4 && wave == 0) { issue_piece(qt + 2, nb, 4); issue_piece(qt + 2, nb, 5); }
+            if (c < 4) issue_piece(qt2, nb, c);
+            else if (c == 4 && wave == 0) { issue_piece(qt2, nb, 4); issue_piece(qt2, nb, 5); }
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s), "+v"(dp));
@@ -1769,7 +1861,10 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         DSTAMP(4 + 5 * (qt - qt0));
         // tile qt+1 has landed when at most the pieces of tile qt+2 are outstanding (wave 0 also carries the two statistics pieces);
         // lgkmcnt(0): this wave's LDS reads of tile qt (transpose reads, lse / delta) have returned, so after the barrier its slot is dead
-        if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        // (PERS, first tile of a later key block: tile qt+1 was waited for -- vmcnt(0) -- at the switch, BEFORE the dK / dV stores and the
+        //  staging DMA were issued; a counted wait here would have to count those)
+        if (PERS && first) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); first = false; }
+        else if (wave == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1787,10 +1882,52 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         }
         DSTAMP(5 + 5 * (qt - qt0));
     }
-#undef MFMA_ACC
-#undef MFMA_ACC_MEM
     // the accumulators were last written by asm MFMAs hipcc knows nothing about: 18+ wait states before it reads them out of the AGPRs
     asm volatile("s_nop 15\n\ts_nop 3" : "+a"(dk[0]), "+a"(dk[1]), "+a"(dk[2]), "+a"(dk[3]), "+a"(dv[0]), "+a"(dv[1]), "+a"(dv[2]), "+a"(dv[3]));
+    if constexpr (!PERS) break;
+    else {
+        // ---- switch to the next key block of this head
+        const bool last = rank + 1 >= nkb;
+        DSTAMP(80 + 3 * (rank & 3));
+        // everything in flight lands first (the next tile's pieces were issued most of an iteration ago): the next iteration then needs no
+        // counted wait, whatever number of stores / staging pieces is issued below
+        if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char* const trn = smem + DKV_TRN + wave * 8192;
+        const int64_t dkpo = PAIR ? a.dks.h - 64 : 0, dvpo = PAIR ? a.dvs.h - 64 : 0;
+        store_rows_lds<PAIR>(trn, a.dk + b * a.dks.b + hd * hm * a.dks.h, a.dks.s, kw, a.Sk, dk, a.scale, a.scale, lane, dkpo);
+        store_rows_lds<PAIR>(trn, a.dv + b * a.dvs.b + hd * hm * a.dvs.h, a.dvs.s, kw, a.Sk, dv, 1.0f, 1.0f, lane, dvpo);
+        DSTAMP(81 + 3 * (rank & 3));
+        if (last) break;
+        ++rank;
+        k0 += 128; kw += 128; kj += 128;
+        kok = kj < a.Sk && ((kvbits >> rank) & 1u) != 0u;
+        bias2 = __fmul_rn(sl2, (float)(kj - (a.Sk - 1)));
+        bias2B = __fmul_rn(sl2B, (float)(kj - (a.Sk - 1)));
+        qt0 = qtn;
+        qtn = rank + 1 < nkb ? first_tile_of(k0 + 128) : nqt + 2;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            kf[c] = *reinterpret_cast<const bf16x8_t*>(stK + (qfo ^ (32 * c)));
+            vf[c] = *reinterpret_cast<const bf16x8_t*>(stV + (qfo ^ (32 * c)));
+        }
+#pragma unroll
+        for (int db = 0; db < 4; ++db) { dk[db] = zero16(); dv[db] = zero16(); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging rows are in registers before the next block's rows may land on them
+        if (rank + 1 < nkb) stage_kv(kw + 128);
+        first = true;
+        DSTAMP(82 + 3 * ((rank - 1) & 3));
+    }
+    }
+#undef MFMA_ACC
+#undef MFMA_ACC_MEM
+    if constexpr (PERS) {
+        BLK_END(2);
+#ifdef OTTER_FLASH_TIMING
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < 96 && g_flash_stamps) g_flash_stamps[threadIdx.x] = reinterpret_cast<unsigned long long*>(smem + 50688)[threadIdx.x];
+#endif
+        return;
+    }
     DSTAMP(90);
     if constexpr (PAIR) {
         if (kj < a.Sk) {
@@ -1862,6 +1999,30 @@ int g_flash_variant = 0;
 // at C2 (B=8, 32 heads, S=512) the forward went 54.3 -> 43.7 us and the backward 230 -> 184.5 us per layer with it
 inline bool flash_lpt(const FlashArgs& a) { return a.causal && g_flash_variant != 2 && g_flash_variant != 3; }
 
+// One dK/dV workgroup per (batch, head or head pair) that walks all key blocks (flash_bwd_dkv2_kernel<..., PERS>): when those workgroups fill
+// the chip evenly (a multiple of the CU count, or many rounds of them), every key block has at least two query tiles (the ring runs two
+// tiles ahead across the block switch) and the key-padding bits of all blocks fit one word.  Flash variant 7 switches it off (A/B).
+inline int device_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+inline bool dkv_persistent(const FlashArgs& a) {
+    if (g_flash_variant == 7 || g_flash_variant == 2 || g_flash_variant == 3 || g_flash_variant == 5) return false;
+    const int nkb = (a.Sk + 127) / 128, nqt = (a.Sq + 31) / 32;
+    if (nkb < 2 || nkb > 32) return false;
+    const int imin = (nkb - 1) * 128 - (a.Sk - a.Sq);
+    const int qt_last = a.causal && imin > 0 ? imin >> 5 : 0;
+    if (nqt - qt_last < 2) return false;
+    if (g_flash_variant == 8) return true;   // tests: the persistent form on small launches too
+    const int nwg = a.B * (a.pair ? a.H / 2 : a.H), cus = device_cu_count();
+    return nwg % cus == 0 || nwg >= 8 * cus;
+}
+
 template <typename K>
 int set_smem(K kern, int bytes) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1874,7 +2035,7 @@ int set_smem(K kern, int bytes) {
 extern "C" {
 
 int otter_flash_set_variant(int v) {
-    OTTER_REQUIRE(v >= 0 && v <= 6, "flash variant %d (6 = forward version 3: 16 queries per wave, 16x16x32 MFMA, four waves per SIMD; 0 = default: LDS-DMA v2, LPT block order, delta inside the dQ kernel; 1 = register-staged v1; 2 = v2, plain grid; 3 = 2 + dK/dV at two workgroups per CU; 4 = 0 with the separate flash_delta launch (round-3 order); 5 = 0 + dK/dV at two workgroups per CU)", v);
+    OTTER_REQUIRE(v >= 0 && v <= 8, "flash variant %d (8 = 0 with the persistent dK/dV form on every launch it can address; 7 = 0 with one dK/dV workgroup per key block instead of the persistent per-head form; 6 = forward version 3: 16 queries per wave, 16x16x32 MFMA, four waves per SIMD; 0 = default: LDS-DMA v2, LPT block order, delta inside the dQ kernel; 1 = register-staged v1; 2 = v2, plain grid; 3 = 2 + dK/dV at two workgroups per CU; 4 = 0 with the separate flash_delta launch (round-3 order); 5 = 0 + dK/dV at two workgroups per CU)", v);
     g_flash_variant = v;
     return OTTER_OK;
 }
@@ -1965,6 +2126,7 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
         if (!once) {
             rc = set_smem(flash_bwd_dkv2_kernel<1, false, true>, smem_kv); if (rc) return rc;
             rc = set_smem(flash_bwd_dkv2_kernel<1, true, true>, smem_kv); if (rc) return rc;
+            rc = set_smem((flash_bwd_dkv2_kernel<1, true, true, true>), DKV_PERS_SMEM); if (rc) return rc;
             rc = set_smem(flash_bwd_dq2_kernel<false, true, true>, smem_q); if (rc) return rc;
             rc = set_smem(flash_bwd_dq2_kernel<true, true, true>, smem_q); if (rc) return rc;
             rc = set_smem(flash_bwd_dq2_kernel<false, true, false>, smem_q); if (rc) return rc;
@@ -1973,6 +2135,7 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
         }
         const unsigned nkb = (unsigned)((a.Sk + 127) / 128), nqb = (unsigned)((a.Sq + 127) / 128), hb = (unsigned)(a.H / 2);
         auto launch_dkv = [&]() {
+            if (dkv_persistent(a)) { hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, true, true>), dim3(hb * a.B), dim3(256), DKV_PERS_SMEM, st, a); return; }
             if (flash_lpt(a)) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, true>), dim3(nkb * hb * a.B), dim3(256), smem_kv, st, a);
             else hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, false, true>), dim3(nkb, hb, a.B), dim3(256), smem_kv, st, a);
         };
@@ -2001,6 +2164,7 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
             rc = set_smem(flash_bwd_dkv2_kernel<2, false, false>, smem_kv); if (rc) return rc;
             rc = set_smem(flash_bwd_dkv2_kernel<1, true, false>, smem_kv); if (rc) return rc;
             rc = set_smem(flash_bwd_dkv2_kernel<2, true, false>, smem_kv); if (rc) return rc;
+            rc = set_smem((flash_bwd_dkv2_kernel<1, true, false, true>), DKV_PERS_SMEM); if (rc) return rc;
             rc = set_smem((flash_bwd_dq2_kernel<false, false, true>), smem_q); if (rc) return rc;
             rc = set_smem((flash_bwd_dq2_kernel<true, false, true>), smem_q); if (rc) return rc;
             once = true;
@@ -2008,6 +2172,7 @@ int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream) {
         const unsigned nkb = (unsigned)((a.Sk + 127) / 128);
         const unsigned nqb = (unsigned)((a.Sq + 127) / 128);
         auto launch_dkv = [&]() {
+            if (dkv_persistent(a)) { hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, false, true>), dim3(a.H * a.B), dim3(256), DKV_PERS_SMEM, st, a); return; }
             if (g_flash_variant == 3) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, false, false>), dim3(nkb, a.H, a.B), dim3(256), smem_kv, st, a);
             else if (flash_lpt(a) && g_flash_variant != 5) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<1, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);
             else if (g_flash_variant == 5 && a.causal) hipLaunchKernelGGL((flash_bwd_dkv2_kernel<2, true, false>), dim3(nkb * a.H * a.B), dim3(256), smem_kv, st, a);

@@ -54,7 +54,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])   # 8: the persistent dK/dV kernel wherever a launch has >= 2 key blocks
 @pytest.mark.parametrize("B,H,S,causal,alibi,lens", CASES)
 def test_flash_attention_fwd_bwd(ops, B, H, S, causal, alibi, lens, variant):
     from otter_amd.mpt import alibi_slopes
@@ -129,7 +129,7 @@ def _views64(layout, B, S, H, g, fill=None):
     return [buf], [buf[:, :, i] for i in range(3)]
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 8])
 @pytest.mark.parametrize("layout", ["compact", "interleaved", "fused"])
 @pytest.mark.parametrize("B,H,S,causal,alibi,lens", CASES64)
 def test_flash_attention_head_dim_64(ops, B, H, S, causal, alibi, lens, layout, variant):
@@ -277,6 +277,55 @@ def test_mpt_host_flash_matches_sdpa_path(ops, monkeypatch):
     valid = am.bool().cpu().numpy()
     assert relmax(lf[valid], ls[valid]) < 2e-2
     assert relmax(gf, gs) < 3e-2
+
+
+@pytest.mark.parametrize("B,H,S,lens", [(8, 32, 512, None), (8, 32, 384, [384, 300, 129, 128, 127, 384, 1, 200]), (1, 256, 256, None)])
+def test_flash_persistent_dkv_equals_per_block_kernel(ops, B, H, S, lens):
+    """The benchmark's launch (B x H = 256 = one dK/dV workgroup per CU) takes the persistent per-head kernel (flash.hip: PERS): the same
+    tiles in the same order per key block as the one-workgroup-per-key-block kernel (variant 7), K / V fragments through an LDS staging
+    area instead of global loads, results out through an LDS transpose.  dQ (same kernel) is bit-identical; dK / dV agree to the bf16
+    rounding of single P / dS elements (the two instantiations compile the fp32 softmax to different instruction sequences: an fp32 last
+    bit now and then flips the bf16 rounding of a P element; tools/flash_pers_diff.py: 2 271 of 16.7 M dK elements, both forms equally
+    far from an fp64 reference) -- and dK / dV right against the oracle on two heads."""
+    from otter_amd.mpt import alibi_slopes
+
+    g = torch.Generator().manual_seed(B + S)
+    qkv = (torch.randn(B, S, 3, H, 128, generator=g) * 0.8).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B, S, H, 128, generator=g).to(torch.bfloat16).to(DEV)
+    sl = alibi_slopes(H, 8).float().to(DEV)
+    kvd = None
+    if lens is not None:
+        kvd = torch.zeros(B, S, dtype=torch.uint8)
+        for b, n in enumerate(lens):
+            kvd[b, :n] = 1
+        kvd = kvd.to(DEV)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    scale = 1.0 / math.sqrt(128)
+    outs = []
+    for variant in (0, 7, 0):
+        ops.set_flash_variant(variant)
+        o, lse = ops.flash_attn_fwd(q, k, v, sl, kvd, scale, True)
+        d = torch.full_like(qkv, float("nan"))
+        ops.flash_attn_bwd(q, k, v, o, lse, dout, d[:, :, 0], d[:, :, 1], d[:, :, 2], sl, kvd, scale, True)
+        outs.append(d)
+    ops.set_flash_variant(0)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(outs[0].float()).any())
+    assert torch.equal(outs[0], outs[2])                       # run to run
+    assert torch.equal(outs[0][:, :, 0], outs[1][:, :, 0])     # dQ
+    for i in (1, 2):
+        a_, b_ = outs[0][:, :, i].float(), outs[1][:, :, i].float()
+        diff = (a_ - b_).abs()
+        assert float(diff.max()) <= float(b_.abs().max()) * 2.0 ** -7
+        assert float((diff > 0).float().mean()) < 1e-3
+    hs = [0, H - 1]
+    f = lambda t: t.float().cpu().double().numpy().transpose(0, 2, 1, 3)
+    bsel = slice(B - 1, B)
+    qh, kh, vh = (f(qkv[bsel, :, i][:, :, hs]) for i in range(3))
+    _, (rdq, rdk, rdv) = O.mpt_attention_core(qh, kh, vh, scale, sl.cpu().numpy()[hs], kvd.cpu().numpy()[bsel] if kvd is not None else None, True,
+                                              f(dout[bsel][:, :, hs]))
+    assert relmax(f(outs[0][bsel, :, 1][:, :, hs]), rdk) < 2e-2
+    assert relmax(f(outs[0][bsel, :, 2][:, :, hs]), rdv) < 2e-2
 
 
 def test_flash_block_order_is_only_an_order(ops):

@@ -30,6 +30,9 @@ for it in range(16):
     rows.append({"it": it, "top": rel(b), "S,dP+reads+dma": t[b + 1] - t[b], "softmax A": t[b + 2] - t[b + 1], "dV,dK(0)+softmax B": t[b + 3] - t[b + 2],
                  "barrier+dV,dK(1)+row reads": t[b + 4] - t[b + 3]})
 print(json.dumps({"prologue_to_loop": rel(1), "loop_end": rel(90), "stores_done": rel(91)}))
+# persistent per-head kernel: per key block (rank) the end of its tile loop, its stores issued, the switch done (slots 80 + 3 rank ..)
+print(json.dumps({"persistent_switches": [{"rank": r, "loop_end": rel(80 + 3 * r), "stores_issued": rel(81 + 3 * r) - rel(80 + 3 * r),
+                                           "switch_rest": (rel(82 + 3 * r) - rel(81 + 3 * r)) if r < 3 else None} for r in range(4)]}))
 for r in rows:
     print(json.dumps(r))
 # forward (v2), block 0 = the last query tile of (batch 0, head 0): 8 key tiles
