@@ -442,6 +442,40 @@ class FrozenMLPFn(torch.autograd.Function):
         return dx, None, None
 
 
+class FrozenMLPFusedLegsFn(torch.autograd.Function):
+    """The frozen decoder MLP with ONLY its two fusable products on csrc/gemm.hip -- up_proj with GELU in the tail (u kept beside it) and
+    down_proj's input gradient with GELU' in the tail, read against the weight as stored (K-major kernel: no transposed copy of down_proj) --
+    and the two plain products (down_proj forward, up_proj input gradient against its transposed copy) on hipBLASLt.  Per-shape A/B at C2
+    (tools/decoder_gemm_ab.py, profiles/r04_decoder_gemm_ab.txt): fused up 396.6 us vs library + gelu_fwd 398.8, fused down-dgrad 414.4 vs
+    library + gelu_bwd 419.7; the plain products are 2-7 % faster on the library."""
+
+    @staticmethod
+    def forward(ctx, x2, Wu, Wd, Wu_t):
+        need = ctx.needs_input_grad[0]
+        u = torch.empty((x2.shape[0], Wu.shape[0]), dtype=x2.dtype, device=x2.device) if need else None
+        h = ops.gemm_nt(x2, Wu, kind=EPI_GELU, C2=u)
+        y = torch.nn.functional.linear(h, Wd)
+        if need:
+            ctx.save_for_backward(u, Wd, Wu_t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, Wd, Wu_t = ctx.saved_tensors
+        dy = dy.contiguous() if dy.dtype == u.dtype else dy.to(u.dtype).contiguous()
+        if ops.gemm_kmajor_supported(dy.shape[0], Wd.shape[1], Wd.shape[0], dy.stride(0), Wd.stride(0), False, True, dy.dtype):
+            du = ops.gemm(dy, Wd, False, True, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+        else:
+            du = ops.gemm_nt(dy, ops.transpose(Wd, Wd.dtype), kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+        return torch.nn.functional.linear(du, Wu_t), None, None, None
+
+
+def frozen_mlp_fused_legs(x, Wu, Wd, Wu_t):
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    return FrozenMLPFusedLegsFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), Wu, Wd, Wu_t).view(shp[:-1] + (Wd.shape[0],))
+
+
 def frozen_mlp(x, Wu, Wd):
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])

@@ -112,6 +112,12 @@ def _own_gemm() -> bool:
     return os.environ.get("OTTER_OWN_DECODER_GEMM") == "1"
 
 
+def _own_mlp_fused_legs() -> bool:
+    """OTTER_OWN_DECODER_GEMM=mlp: only the two products of the frozen MLP that carry a fusion (up_proj + GELU, down_proj's input gradient +
+    GELU') on csrc/gemm.hip, the plain products on hipBLASLt (functional.FrozenMLPFusedLegsFn)."""
+    return os.environ.get("OTTER_OWN_DECODER_GEMM") == "mlp"
+
+
 def _lin(x, w):
     return F.linear(x, w)
 
@@ -190,6 +196,11 @@ class MPTMLP(nn.Module):
                 and OF.compute_dtype_for(x) == torch.bfloat16):
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
             return OF.frozen_mlp(xb, up._copy_w(torch.bfloat16), dn._copy_w(torch.bfloat16))
+        if (_own_mlp_fused_legs() and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and up.bias is None and dn.bias is None
+                and not up.weight.requires_grad and not dn.weight.requires_grad and OF.compute_dtype_for(x) == torch.bfloat16):
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            wu, wu_t = up._copies(torch.bfloat16)
+            return OF.frozen_mlp_fused_legs(xb, wu, dn._copy_w(torch.bfloat16), wu_t)
         u = self.up_proj(x)
         if u.is_cuda and os.environ.get("OTTER_TORCH_GELU") != "1":
             return self.down_proj(OF.gelu(u))      # csrc/elementwise.hip gelu_fwd / gelu_bwd (same exact-erf form as nn.GELU())
