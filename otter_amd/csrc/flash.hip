@@ -2014,7 +2014,7 @@ inline int device_cu_count() {
 inline bool dkv_persistent(const FlashArgs& a) {
     if (g_flash_variant == 7 || g_flash_variant == 2 || g_flash_variant == 3 || g_flash_variant == 5) return false;
     const int nkb = (a.Sk + 127) / 128, nqt = (a.Sq + 31) / 32;
-    if (nkb < 2 || nkb > 32) return false;
+    if (nkb < 2 || nkb > 32 || a.Sq != a.Sk) return false;   // (the backward is a training launch: square; nothing else is tested in this form)
     const int imin = (nkb - 1) * 128 - (a.Sk - a.Sq);
     const int qt_last = a.causal && imin > 0 ? imin >> 5 : 0;
     if (nqt - qt_last < 2) return false;
