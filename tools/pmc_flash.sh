@@ -9,7 +9,7 @@ C[1]="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_
 C[2]="SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY"
 for i in 1 2; do
   rm -rf /tmp/pf_$i
-  timeout -k 5 120 rocprofv3 --kernel-trace --pmc ${C[$i]} --output-format csv -d /tmp/pf_$i -o p -- python $CMD > /tmp/pf_$i.log 2>&1
+  timeout -k 5 60 rocprofv3 --kernel-trace --pmc ${C[$i]} --output-format csv -d /tmp/pf_$i -o p -- python $CMD > /tmp/pf_$i.log 2>&1
   f=$(find /tmp/pf_$i -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then tail -5 /tmp/pf_$i.log; continue; fi
   python - "$f" "$ROOT/$OUT/pass$i.json" <<'PY'
