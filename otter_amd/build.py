@@ -84,6 +84,18 @@ def build_flash_define(define: str, suffix: str, verbose: bool = True) -> str:
     return out
 
 
+def build_source_define(source: str, define: str, suffix: str, verbose: bool = True) -> str:
+    """A/B build of one source file with one extra -D -> lib/libotter_hip_<suffix>.so (tools only, via OTTER_LIB_PATH)."""
+    build(verbose=verbose)
+    cc = hipcc()
+    obj = os.path.join(LIBDIR, "%s_%s.o" % (source.replace(".hip", ""), suffix))
+    out = os.path.join(LIBDIR, "libotter_hip_%s.so" % suffix)
+    subprocess.check_call([cc, *FLAGS, *EXTRA.get(source, []), "-D" + define, "-c", os.path.join(CSRC, source), "-o", obj])
+    others = [os.path.join(LIBDIR, s.replace(".hip", ".o")) for s in SOURCES if s != source]
+    subprocess.check_call([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, obj, *others])
+    return out
+
+
 def build_flash_timing(verbose: bool = True) -> str:
     """Diagnostics build with the in-kernel timeline of the flash forward (-DOTTER_FLASH_TIMING) ->
     lib/libotter_hip_flashtiming.so; only tools/flash_timeline.py loads it."""
@@ -132,6 +144,9 @@ if __name__ == "__main__":
     elif "--flash-define" in sys.argv:
         i = sys.argv.index("--flash-define")
         print(build_flash_define(sys.argv[i + 1], sys.argv[i + 2]))
+    elif "--src-define" in sys.argv:      # --src-define norm.hip OTTER_NORM_NT=1 normnt
+        i = sys.argv.index("--src-define")
+        print(build_source_define(sys.argv[i + 1], sys.argv[i + 2], sys.argv[i + 3]))
     elif "--experimental" in sys.argv:
         print(build_experimental())
     elif "--flash-timing" in sys.argv:

@@ -296,6 +296,32 @@ __device__ __forceinline__ void ld4(const void* p, int64_t idx, int dt, float (&
         v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
     }
 }
+// streaming loads of the coalesced row kernels (-DOTTER_NORM_NT=mask A/B builds: bit 0 = the fp32 stream x, bit 1 = the bf16 branch dy /
+// delta, bit 2 = the incoming fp32 residual gradient): non-temporal = no allocation in L2 / the Infinity Cache for bytes read once.
+// Measured (round 4, cold operands, profiles/r04_norm_nt_ab.txt): forward kernels 6 % SLOWER (24.9 -> 26.5, 41.2 -> 43.5 us), backward 3-5 %
+// faster (47.6 -> 45.2-46.7), the training step unchanged (127.4-127.8 vs 127.5-128.2 ms) -- default stays 0.
+#ifndef OTTER_NORM_NT
+#define OTTER_NORM_NT 0
+#endif
+template <bool NT>
+__device__ __forceinline__ void ld4f_s(const float* p, int64_t idx, float (&v)[4]) {
+    typedef float f4v_ __attribute__((ext_vector_type(4)));
+    if constexpr (NT) {
+        const f4v_ r = __builtin_nontemporal_load(reinterpret_cast<const f4v_*>(p + idx));
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    } else {
+        const float4 r = *reinterpret_cast<const float4*>(p + idx);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ uint2 ld4bf_raw_s(const bf16_t* p, int64_t idx) {
+    typedef unsigned u2v_ __attribute__((ext_vector_type(2)));
+    if constexpr (NT) {
+        const u2v_ r = __builtin_nontemporal_load(reinterpret_cast<const u2v_*>(p + idx));
+        return make_uint2(r.x, r.y);
+    } else return *reinterpret_cast<const uint2*>(p + idx);
+}
 __device__ __forceinline__ void st4bf(bf16_t* p, int64_t idx, const float (&v)[4]) {
     uint2 r;
     r.x = pack2bf(v[0], v[1]);
@@ -324,10 +350,14 @@ __global__ __launch_bounds__(256) void norm_fwd_c_kernel(const float* __restrict
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int64_t o = base + c * 512 + h * 256;
-                ld4(x, o, OTTER_F32, v[c][h]);
+                ld4f_s<(OTTER_NORM_NT & 1) != 0>(x, o, v[c][h]);
                 if (delta) {
                     float dl[4];
-                    ld4(delta, o, ddt, dl);
+                    if ((OTTER_NORM_NT & 2) && ddt == OTTER_BF16) {
+                        const uint2 r = ld4bf_raw_s<true>((const bf16_t*)delta, o);
+                        dl[0] = __uint_as_float(r.x << 16); dl[1] = __uint_as_float(r.x & 0xffff0000u);
+                        dl[2] = __uint_as_float(r.y << 16); dl[3] = __uint_as_float(r.y & 0xffff0000u);
+                    } else ld4(delta, o, ddt, dl);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[c][h][i] += dl[i];
                     st4f(xsum, o, v[c][h]);
@@ -412,8 +442,8 @@ void norm_bwd_dx_c_kernel(const bf16_t* __restrict__ dy, otter_rowmap dymap, con
         if (c < nrun) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                ld4(x, base + c * 512 + h * 256, OTTER_F32, xr[c][h]);
-                dr[c][h] = *reinterpret_cast<const uint2*>(dy + dbase + c * 512 + h * 256);
+                ld4f_s<(OTTER_NORM_NT & 1) != 0>(x, base + c * 512 + h * 256, xr[c][h]);
+                dr[c][h] = ld4bf_raw_s<(OTTER_NORM_NT & 2) != 0>(dy, dbase + c * 512 + h * 256);
             }
         }
 #pragma unroll
@@ -444,7 +474,7 @@ void norm_bwd_dx_c_kernel(const bf16_t* __restrict__ dy, otter_rowmap dymap, con
                 const int64_t o = base + c * 512 + h * 256;
                 float gm[4], r[4], out[4];
                 if (gamma) ld4(gamma, c * 512 + h * 256 + lane * 4, wdt, gm);
-                if (dres) ld4(dres, o, OTTER_F32, r);
+                if (dres) ld4f_s<(OTTER_NORM_NT & 4) != 0>(dres, o, r);
                 const float dv[4] = {__uint_as_float(dr[c][h].x << 16), __uint_as_float(dr[c][h].x & 0xffff0000u),
                                      __uint_as_float(dr[c][h].y << 16), __uint_as_float(dr[c][h].y & 0xffff0000u)};
 #pragma unroll
