@@ -328,6 +328,37 @@ def test_flash_persistent_dkv_equals_per_block_kernel(ops, B, H, S, lens):
     assert relmax(f(outs[0][bsel, :, 2][:, :, hs]), rdv) < 2e-2
 
 
+def test_flash_backward_repeats_bit_for_bit_under_load(ops):
+    """300 launches of forward + backward at the benchmark's launch shape (persistent dK/dV form), part of them with unrelated traffic on a
+    second stream: every result equals the first one bit for bit -- a race between the DMA ring, the K / V staging area and the LDS
+    transpose of the persistent kernel would show as a run-to-run difference (tools/flash_stress.py runs thousands)."""
+    from otter_amd.mpt import alibi_slopes
+
+    B, H, S = 8, 32, 512
+    g = torch.Generator().manual_seed(77)
+    qkv = (torch.randn(B, S, 3, H, 128, generator=g) * 0.8).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B, S, H, 128, generator=g).to(torch.bfloat16).to(DEV)
+    sl = alibi_slopes(H, 8).float().to(DEV)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    scale = 1.0 / math.sqrt(128)
+    o, lse = ops.flash_attn_fwd(q, k, v, sl, None, scale, True)
+    ref = torch.full_like(qkv, float("nan"))
+    ops.flash_attn_bwd(q, k, v, o, lse, dout, ref[:, :, 0], ref[:, :, 1], ref[:, :, 2], sl, None, scale, True)
+    side, junk = torch.cuda.Stream(), torch.empty(32 << 20, device=DEV)
+    d = torch.empty_like(qkv)
+    bad = 0
+    for it in range(300):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.add_(1.0)
+        d.fill_(float("nan"))
+        o2, lse2 = ops.flash_attn_fwd(q, k, v, sl, None, scale, True)
+        ops.flash_attn_bwd(q, k, v, o2, lse2, dout, d[:, :, 0], d[:, :, 1], d[:, :, 2], sl, None, scale, True)
+        bad += int(not (torch.equal(d, ref) and torch.equal(o2, o)))
+    torch.cuda.synchronize()
+    assert bad == 0
+
+
 def test_flash_block_order_is_only_an_order(ops):
     """Longest-first block order, also in GROUPS of heads (B*H = 160 heads x 1024 tokens = 80 MB of K + V > the 64 MB group budget ->
     groups of 80 heads), against the plain 3-D grid: the same blocks do the same arithmetic, so every output is bit-identical."""
