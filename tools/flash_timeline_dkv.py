@@ -1,4 +1,4 @@
-"""In-kernel timeline (s_memtime ticks, 100 MHz -> 10 ns each) of the first dK/dV workgroup (key block 0: 16 query tiles at S=512) of the
+"""In-kernel timeline (s_memtime ticks = shader-clock cycles, ~1.9-2.1 per ns against the 10 ns stamps of tools/flash_launch_picture.py) of the first dK/dV workgroup (key block 0: 16 query tiles at S=512) of the
 decoder-host flash attention backward.  Needs `python -m otter_amd.build --flash-timing` and
 OTTER_LIB_PATH=otter_amd/lib/libotter_hip_flashtiming.so."""
 import ctypes, json, math, os, sys
