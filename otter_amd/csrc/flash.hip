@@ -37,6 +37,10 @@ constexpr int LDT = HD + 32;  // transpose-read tiles (320-B rows)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
+#ifndef OTTER_FLASH_ROWSTORE
+#define OTTER_FLASH_ROWSTORE 1   // O, dQ and the per-block dK / dV leave through an LDS transpose as whole 256-byte rows (store_rows_lds), like dK / dV of the
+                                 // persistent kernel; 0 (A/B builds) = the 8-byte-per-row stores of store_dt.  Round 4, C2: forward 43.9 -> 41.7 us
+#endif
 struct Str { int64_t b, s, h; };  // element strides of a [B, S, H, 128] view
 
 struct FlashArgs {
@@ -164,6 +168,35 @@ __device__ __forceinline__ void store_dt_pair(bf16_t* rowp, const f32x16_t (&acc
             w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
             *reinterpret_cast<uint2*>(rowp + 32 * db + 8 * g + 4 * h2 + (db >= 2 ? poff : 0)) = w;
         }
+    }
+}
+
+// Output rows of one wave (32 rows x 128: dK / dV of the persistent kernel; -DOTTER_FLASH_ROWSTORE=1 A/B builds: O and dQ too) from the
+// S^T-orientation accumulators to global memory through LDS: lane (ql, h2) holds
+// d = 32 db + 8 g + 4 h2 + e of key ql; written as 8-B pieces into a 16-B-slot-swizzled row-major tile, read back as 16 B per lane,
+// four whole rows per store instruction
+template <bool PAIR>
+__device__ __forceinline__ void store_rows_lds(char* trn, bf16_t* base, int64_t row_stride, int row0, int nrows_valid, const f32x16_t (&acc)[4],
+                                               float mul0, float mul1, int lane, int64_t poff) {
+    const int ql = lane & 31, h2 = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const float mul = (PAIR && db >= 2) ? mul1 : mul0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
+            w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
+            *reinterpret_cast<uint2*>(trn + ql * 256 + (((4 * db + g) ^ (ql & 15)) << 4) + 8 * h2) = w;
+        }
+    }
+    const int p = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + (lane >> 4);
+        const uint4 w = *reinterpret_cast<const uint4*>(trn + row * 256 + ((p ^ (row & 15)) << 4));
+        if (row0 + row < nrows_valid)
+            *reinterpret_cast<uint4*>(base + (int64_t)(row0 + row) * row_stride + 8 * p + ((PAIR && p >= 8) ? poff : 0)) = w;
     }
 }
 
@@ -673,6 +706,15 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
     if constexpr (PAIR) {
         lsumB += __shfl_xor(lsumB, 32, 64);
         const float invB = lsumB > 0.f ? 1.0f / lsumB : 0.f;
+#if OTTER_FLASH_ROWSTORE
+        __builtin_amdgcn_s_barrier();
+        store_rows_lds<true>(smem + wave * 8192, a.o + b * a.os.b + hd * 2 * a.os.h, a.os.s, q0 + wave * 32, a.Sq, o, inv, invB, lane, a.os.h - 64);
+        if (qi < a.Sq && h2 == 0) {
+            float* lp = a.lse + ((int64_t)b * a.H + hd * 2) * a.Sq + qi;
+            lp[0] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
+            lp[a.Sq] = lsumB > 0.f ? mB * LN2 + logf(lsumB) : -INFINITY;
+        }
+#else
         if (qi < a.Sq) {
             store_dt_pair(a.o + b * a.os.b + hd * 2 * a.os.h + (int64_t)qi * a.os.s, o, inv, invB, h2, a.os.h - 64);
             if (h2 == 0) {
@@ -681,12 +723,19 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
                 lp[a.Sq] = lsumB > 0.f ? mB * LN2 + logf(lsumB) : -INFINITY;
             }
         }
+#endif
         return;
     }
+#if OTTER_FLASH_ROWSTORE
+    __builtin_amdgcn_s_barrier();   // every wave is done with the last K / V tile: its LDS is free for the row-major staging of O
+    store_rows_lds<false>(smem + wave * 8192, a.o + b * a.os.b + hd * a.os.h, a.os.s, q0 + wave * 32, a.Sq, o, inv, inv, lane, 0);
+    if (qi < a.Sq && h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
+#else
     if (qi < a.Sq) {
         store_dt(a.o + b * a.os.b + hd * a.os.h + (int64_t)qi * a.os.s, o, inv, h2);
         if (h2 == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + qi] = lsum > 0.f ? m * LN2 + logf(lsum) : -INFINITY;
     }
+#endif
     BLK_END(0);
 #ifdef OTTER_FLASH_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1379,10 +1428,20 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
         }
     }
     if constexpr (PAIR) {
+#if OTTER_FLASH_ROWSTORE
+        __builtin_amdgcn_s_barrier();
+        store_rows_lds<true>(smem + wave * 8192, a.dq + b * a.dqs.b + hd * 2 * a.dqs.h, a.dqs.s, q0 + wave * 32, a.Sq, dq, a.scale, a.scale, lane, a.dqs.h - 64);
+#else
         if (qi < a.Sq) store_dt_pair(a.dq + b * a.dqs.b + hd * 2 * a.dqs.h + (int64_t)qi * a.dqs.s, dq, a.scale, a.scale, h2, a.dqs.h - 64);
+#endif
         return;
     }
+#if OTTER_FLASH_ROWSTORE
+    __builtin_amdgcn_s_barrier();
+    store_rows_lds<false>(smem + wave * 8192, a.dq + b * a.dqs.b + hd * a.dqs.h, a.dqs.s, q0 + wave * 32, a.Sq, dq, a.scale, a.scale, lane, 0);
+#else
     if (qi < a.Sq) store_dt(a.dq + b * a.dqs.b + hd * a.dqs.h + (int64_t)qi * a.dqs.s, dq, a.scale, h2);
+#endif
     BLK_END(1);
 }
 
@@ -1395,34 +1454,6 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
 constexpr int DKV_STG = 52224;              // PERS: K | V of the NEXT key block, 2 x 8 KB per wave
 constexpr int DKV_TRN = DKV_STG + 65536;    // PERS: 8 KB per wave for the row-major dK / dV tile on its way out
 constexpr int DKV_PERS_SMEM = DKV_TRN + 32768;
-
-// dK / dV rows of one wave (32 keys x 128) from the S^T-orientation accumulators to global memory through LDS: lane (ql, h2) holds
-// d = 32 db + 8 g + 4 h2 + e of key ql; written as 8-B pieces into a 16-B-slot-swizzled row-major tile, read back as 16 B per lane,
-// four whole rows per store instruction
-template <bool PAIR>
-__device__ __forceinline__ void store_rows_lds(char* trn, bf16_t* base, int64_t row_stride, int row0, int nrows_valid, const f32x16_t (&acc)[4],
-                                               float mul0, float mul1, int lane, int64_t poff) {
-    const int ql = lane & 31, h2 = lane >> 5;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-        const float mul = (PAIR && db >= 2) ? mul1 : mul0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 w;
-            w.x = pack2bf(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul);
-            w.y = pack2bf(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
-            *reinterpret_cast<uint2*>(trn + ql * 256 + (((4 * db + g) ^ (ql & 15)) << 4) + 8 * h2) = w;
-        }
-    }
-    const int p = lane & 15;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + (lane >> 4);
-        const uint4 w = *reinterpret_cast<const uint4*>(trn + row * 256 + ((p ^ (row & 15)) << 4));
-        if (row0 + row < nrows_valid)
-            *reinterpret_cast<uint4*>(base + (int64_t)(row0 + row) * row_stride + 8 * p + ((PAIR && p >= 8) ? poff : 0)) = w;
-    }
-}
 
 template <int MINB, bool LPT, bool PAIR = false, bool PERS = false>   // PAIR: two 64-wide heads per workgroup, see flash_fwd2_kernel
 __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) {
@@ -1929,6 +1960,16 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         return;
     }
     DSTAMP(90);
+#if OTTER_FLASH_ROWSTORE
+    {   // the Q / dO ring is dead once every wave has left the loop: 8 KB of it per wave stage the row-major dK / dV tiles
+        __builtin_amdgcn_s_barrier();
+        char* const trn = smem + wave * 8192;
+        const int64_t dkpo = PAIR ? a.dks.h - 64 : 0, dvpo = PAIR ? a.dvs.h - 64 : 0;
+        store_rows_lds<PAIR>(trn, a.dk + b * a.dks.b + hd * hm * a.dks.h, a.dks.s, kw, a.Sk, dk, a.scale, a.scale, lane, dkpo);
+        store_rows_lds<PAIR>(trn, a.dv + b * a.dvs.b + hd * hm * a.dvs.h, a.dvs.s, kw, a.Sk, dv, 1.0f, 1.0f, lane, dvpo);
+    }
+    if constexpr (PAIR) return;
+#else
     if constexpr (PAIR) {
         if (kj < a.Sk) {
             store_dt_pair(a.dk + b * a.dks.b + hd * 2 * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, a.scale, h2, a.dks.h - 64);
@@ -1940,6 +1981,7 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
         store_dt(a.dk + b * a.dks.b + hd * a.dks.h + (int64_t)kj * a.dks.s, dk, a.scale, h2);
         store_dt(a.dv + b * a.dvs.b + hd * a.dvs.h + (int64_t)kj * a.dvs.s, dv, 1.0f, h2);
     }
+#endif
     BLK_END(2);
 #ifdef OTTER_FLASH_TIMING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
