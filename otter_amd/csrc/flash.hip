@@ -2024,6 +2024,9 @@ int fill_args(const otter_flash_desc* d, FlashArgs& a, bool bwd) {
                 if (nbh % c == 0) { g = c; break; }
             if (g == 0) g = nbh;
         }
+        // (experiment hook: OTTER_FLASH_LPT_GROUP=n forces the group size when it divides the block count)
+        static const int forced = [] { const char* e = getenv("OTTER_FLASH_LPT_GROUP"); return e ? atoi(e) : 0; }();
+        if (forced > 0 && nbh % forced == 0) g = forced;
         a.lpt_group = (int)g;
     }
     if (bwd) {
