@@ -267,8 +267,11 @@ typedef struct otter_flash_desc {
 } otter_flash_desc;
 
 int otter_flash_attn_fwd(const otter_flash_desc* d, void* stream);
-/* tuning / A-B hook: 0 = default (LDS-DMA tiles, longest-first block order under the causal mask), 1 = register-staged tiles (v1),
- * 2 = LDS-DMA tiles on the plain 3-D grid, 3 / 5 = 2 / 0 with dK+dV at two workgroups per CU, 4 = 0 (head_dim 64: 1 is refused, 3 / 5 = 2 / 0) */
+/* tuning / A-B hook: 0 = default (LDS-DMA tiles, longest-first block order under the causal mask, delta inside the dQ kernel, one persistent
+ * dK/dV workgroup per (batch, head) when those fill the chip evenly), 1 = register-staged tiles (v1), 2 = LDS-DMA tiles on the plain 3-D grid,
+ * 3 / 5 = 2 / 0 with dK+dV at two workgroups per CU, 4 = 0 with the separate delta launch, 6 = 0 with forward version 3 (16 queries per
+ * wave), 7 = 0 with one dK/dV workgroup per key block, 8 = 0 with the persistent dK/dV form on every launch that can take it
+ * (head_dim 64: 1 is refused, 3 / 5 = 2 / 0) */
 int otter_flash_set_variant(int variant);
 int otter_flash_attn_bwd(const otter_flash_desc* d, void* stream);
 

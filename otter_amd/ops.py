@@ -586,8 +586,9 @@ def set_attn_variant(v: int):
 
 
 def set_flash_variant(v: int):
-    """0 = default (LDS-DMA tiles, longest-first block order), 1 = register-staged tiles, 2 = LDS-DMA tiles on the plain grid, 3-5 = dK/dV
-    occupancy / order variants (A/B hook of the decoder-host flash attention; csrc/flash.hip)."""
+    """0 = default (LDS-DMA tiles, longest-first block order, persistent dK/dV where it applies), 1 = register-staged tiles, 2 = LDS-DMA tiles
+    on the plain grid, 3-5 = dK/dV occupancy / order variants, 6 = forward version 3, 7 = per-key-block dK/dV, 8 = persistent dK/dV wherever
+    it can run (A/B hook of the decoder-host flash attention; csrc/flash.hip, include/otter_hip.h)."""
     K.check(K.lib().otter_flash_set_variant(int(v)), "flash_set_variant")
 
 
