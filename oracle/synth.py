@@ -167,3 +167,31 @@ def tiny_batch(seed=0, B=2, T=16, T_img=1, F=1, image=28):
     labels = np.full((B, T), -100, dtype=np.int64)
     labels[:, 6:T - 1] = ids[:, 6:T - 1]
     return vision_x, ids, mask, labels
+
+
+# ---- the C2-width same-precision comparator case (oracle/gen_golden_bf16ref.py <-> tests/test_gpu_modules.py) ----
+
+
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """fp32 -> nearest bf16 (ties to even) -> fp32, in numpy (bit-identical to torch's .to(bfloat16).float() for finite values)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
+C2REF = dict(seed=53, T=512, row_step=32, dim=4096, dim_visual=1024)
+
+
+def c2_bf16ref_case():
+    """(state dict, x [1,T,D], media [1,1,64,Dv], R [1,T,D], media_locations [1,T]) of the one-sample gated cross-attention block at the
+    benchmark's width: bf16-representable weights / inputs, so that a fp32 run, a bf16-autocast run and the HIP bf16 path see identical
+    numbers and only activation rounding differs."""
+    c = C2REF
+    sd = state_dict_for(c["seed"], gated_xattn_shapes("blk.", c["dim"], c["dim_visual"]))
+    sd = {k: (bf16_round(v) if v.ndim == 2 else v) for k, v in sd.items()}
+    x = bf16_round(tensor(c["seed"], "c2ref.x", (1, c["T"], c["dim"])))
+    media = bf16_round(tensor(c["seed"], "c2ref.m", (1, 1, 64, c["dim_visual"])))
+    R = tensor(c["seed"], "c2ref.R", (1, c["T"], c["dim"]))
+    ml = np.zeros((1, c["T"]), dtype=bool)
+    ml[0, 1] = True          # <image> at position 1 as in the benchmark batch: row 0 precedes it (zeroed attention row)
+    return sd, x, media, R, ml

@@ -1961,7 +1961,11 @@ __global__ __launch_bounds__(256, MINB) void flash_bwd_dkv2_kernel(FlashArgs a) 
     }
     DSTAMP(90);
 #if OTTER_FLASH_ROWSTORE
-    {   // the Q / dO ring is dead once every wave has left the loop: 8 KB of it per wave stage the row-major dK / dV tiles
+    {   // the Q / dO ring is dead once every wave has left the loop: 8 KB of it per wave stage the row-major dK / dV tiles.
+        // The loop issues the LDS-DMA pieces of tiles qt+2 unconditionally (out-of-range tiles read zeros) and its last counted wait
+        // leaves up to 4-6 of them in flight: every wave drains its OWN pieces before the barrier, so that no late DMA write of
+        // another wave can land on the staging rows between store_rows_lds's ds_write and ds_read.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         char* const trn = smem + wave * 8192;
         const int64_t dkpo = PAIR ? a.dks.h - 64 : 0, dvpo = PAIR ? a.dvs.h - 64 : 0;

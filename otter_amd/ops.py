@@ -605,8 +605,10 @@ def gemm_variant_available(v: int) -> bool:
 # Grid shape of the large-grid GEMM launches issued while a `gemm_grid_mode(...)` scope is open (otter_grid_mode in include/otter_hip.h).
 # The scope is a module variable, not a thread-local: the backward products are launched from autograd's device thread, not from the thread
 # that called TrainStep.__call__.  It is set for the duration of ONE training step by the TrainStep that owns a DP reducer and restored
-# when the step returns, so another model (an inference model, a second TrainStep without a reducer) in the same process launches with
-# its own mode -- nothing is left behind in the library.
+# when the step returns -- nothing is left behind in the library.  It is PROCESS-WIDE while that step runs:
+# any other thread that launches GEMMs during the window (an eval thread, a second TrainStep) inherits the mode, and overlapping scopes
+# from two threads restore in LIFO order only if they nest.  The mode affects the grid shape (performance), never results; one training
+# thread per process (the reference's own model: one rank = one Python thread) is what the scope is designed for.
 _grid_mode = K.GRID_DEFAULT
 
 

@@ -90,4 +90,4 @@ def record(name, **vals):
     d = os.path.join(root, "gpurun_out")
     if os.path.isdir(d):
         with open(os.path.join(d, "parity_metrics.jsonl"), "a") as f:
-            f.write(json.dumps({"test": name, **{k: (float(v) if not isinstance(v, (list, str)) else v) for k, v in vals.items()}}) + "\n")
+            f.write(json.dumps({"test": name, **{k: (float(v) if not isinstance(v, (list, str, dict)) else v) for k, v in vals.items()}}) + "\n")
