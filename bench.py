@@ -37,6 +37,70 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; vendor 5 PF figure is 2:1 sparse)
 
+
+
+def machine_calibration(device):
+    """Measured ceilings of THIS box at THIS moment (SURVEY 8d "confirm with a microbenchmark and report measured peaks"),
+    outside the timed region, < 1 s: back-to-back v_mfma_f32_16x16x32_bf16 on every SIMD (otter_probe_mfma: the product GEMM's instruction,
+    no memory traffic) on zero and on random bf16 operands -- the matrix pipe is power-limited on real data --, the shader clock during
+    each (s_memtime / s_memrealtime inside the kernel), and a 1 GiB device-to-device copy."""
+    from otter_amd import _capi as K_
+
+    lib = K_.lib()
+    n_wg = torch.cuda.get_device_properties(device).multi_processor_count
+    g = torch.Generator(device=device).manual_seed(11)
+    rnd = (torch.randn(1 << 19, device=device, generator=g) * 0.05).to(torch.bfloat16)      # 1 MiB of N(0, 0.05) operands
+    zer = torch.zeros(1 << 19, dtype=torch.bfloat16, device=device)
+    out = torch.zeros(2 * n_wg + 256 * n_wg, dtype=torch.int64, device=device)
+    iters = 150_000                                                                          # x 64 MFMAs x 16 cycles = 154 M cycles ~ 70 ms
+    res = {}
+    for tag, src in (("zero_operands", zer), ("random_operands", rnd)):
+        K_.check(lib.otter_probe_mfma(src.data_ptr(), out.data_ptr(), 20_000, n_wg, K_.stream()), "probe_mfma")     # reach the power state
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        K_.check(lib.otter_probe_mfma(src.data_ptr(), out.data_ptr(), iters, n_wg, K_.stream()), "probe_mfma")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        t = out[: 2 * n_wg].view(n_wg, 2).cpu().double()
+        tfl = n_wg * 4 * iters * 1048576.0 / (ms * 1e-3) / 1e12
+        clk = float((t[:, 0] / t[:, 1].clamp(min=1)).median()) * 0.1                         # cycles per 100 MHz tick -> GHz
+        implied = tfl * 1e12 / (n_wg * 4 * 1024.0) / 1e9                                     # 1024 FLOP per SIMD and cycle when issue is back to back
+        res[tag] = {"tflops": round(tfl, 1), "clock_ghz": round(clk if 0.3 < clk < 4.0 else implied, 3), "issue_implied_ghz": round(implied, 3), "ms": round(ms, 1)}
+    nbytes = 1 << 30
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device).fill_(1)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(4):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    res["hbm_copy_tbps"] = round(4 * 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e12, 3)   # bytes read + bytes written
+    res["compute_units"] = n_wg
+    del a, b
+    return res
+
+
+def apply_calibration(out, roof, cal):
+    """Attach the measured ceilings to the JSON line: `frac` stays against the 2.5 PF constant (comparable across rounds and boxes);
+    `frac_of_measured` divides by what back-to-back MFMAs on random operands reach on this box in this run."""
+    if cal is None:
+        return
+    out["calibration"] = cal
+    out["hbm_copy_tbps"] = cal["hbm_copy_tbps"]
+    out["clock_ghz"] = cal["random_operands"]["clock_ghz"]
+    if roof is not None:
+        mp = cal["random_operands"]["tflops"]
+        roof["measured_peak"] = mp
+        roof["measured_peak_zero_operands"] = cal["zero_operands"]["tflops"]
+        roof["frac_of_measured"] = round(roof["achieved"] / mp, 4)
+        gb = roof.get("gated_block")
+        if gb:
+            gb["frac_of_measured"] = round(gb["achieved"] / mp, 4)
+
+
 MPT7B_TEXT = dict(architectures=["MPTForCausalLM"], d_model=4096, n_heads=32, n_layers=32, expansion_ratio=4, max_seq_len=2048,
                   vocab_size=50432, no_bias=True, norm_type="low_precision_layernorm", use_cache=False,
                   attn_config=dict(alibi=True, alibi_bias_max=8, attn_impl="torch", attn_type="multihead_attention"))
@@ -179,7 +243,8 @@ def run_c5(args, device, rank, world, use_dist):
                     "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
         n_par = sum(p.numel() for p in params)
         flops = 6.0 * n_par * B * S + 12.0 * text["num_hidden_layers"] * B * S * S * 4096 * 0.5   # dense 6ND + causal attention fwd+bwd
-        print(json.dumps({
+        cal = machine_calibration(device) if world == 1 else None
+        line = {
             "metric": "image-text pairs/s (train step) OtterHD Fuyu-8B, 1080x1080 image as 1296 patch tokens + %d text tokens" % text_len,
             "value": round(B * world * args.steps / elapsed, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -190,11 +255,13 @@ def run_c5(args, device, rank, world, use_dist):
                        "global_batch": B * world, "seq_len": S, "parallelism": "dp%d" % world},
             "loss": round(float(loss), 4),
             "roofline": roof,
-            "cpu_baseline": None,     # (reported on the BASELINE metric's line only -- config c2; the C5 oracle is a third-party class, tests/test_gpu_modules.py)
+            "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_c5(B, S, text),
             "model_tflops_per_s": round(flops * args.steps / elapsed / 1e12, 1),
             "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1),
             "reserved_mem_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1),
-            "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))}), flush=True)
+            "alloc_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0))}
+        apply_calibration(line, roof, cal)
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -220,12 +287,84 @@ def synth_batch(model, B, T, device, seed, frames=1):
     return vision_x, ids, mask, masking(ids, *tok_ids), tok_ids
 
 
-def cpu_baseline(T=512):
-    """Oracle (numpy port) timed per component on one pair, extrapolated to the whole step by component counts."""
+def _blas_threads():
+    """Threads the host BLAS (numpy's matmul) actually uses: the `cores` field of cpu_baseline (not os.cpu_count())."""
+    try:
+        from threadpoolctl import threadpool_info
+
+        n = [int(i.get("num_threads", 0)) for i in threadpool_info() if i.get("user_api") == "blas"]
+        if n:
+            return max(n)
+    except Exception:
+        pass
+    return os.cpu_count()
+
+
+def _hf_decoder_layer_seconds(kind, T, train_all):
+    """One decoder layer of the reference's third-party host at full width on the host cores (torch CPU, fp32), forward + backward:
+    transformers' LlamaForCausalLM (what the reference instantiates for OTTER-Video-LLaMA7B, modeling_otter.py:54,759-767) or
+    PersimmonForCausalLM (the class the reference's in-repo fuyu/modeling_persimmon.py restates) with ONE layer and a 512-entry
+    vocabulary; frozen host -> input gradient only, OtterHD -> every parameter trains."""
+    if kind == "llama":
+        from transformers import LlamaConfig, LlamaForCausalLM
+
+        cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=1, num_attention_heads=32, num_key_value_heads=32,
+                          vocab_size=512, max_position_embeddings=2048, rms_norm_eps=1e-6)
+        m = LlamaForCausalLM(cfg)
+    else:
+        from transformers import PersimmonConfig, PersimmonForCausalLM
+
+        cfg = PersimmonConfig(hidden_size=4096, intermediate_size=16384, num_hidden_layers=1, num_attention_heads=64, vocab_size=512,
+                              max_position_embeddings=16384, qk_layernorm=True, partial_rotary_factor=0.5, hidden_act="relu2")
+        m = PersimmonForCausalLM(cfg)
+    m = m.float()
+    for p_ in m.parameters():
+        p_.requires_grad_(bool(train_all))
+    x = torch.randn(1, T, 4096).requires_grad_(True)
+    best = None
+    for _ in range(2):     # first pass pays allocation / thread start-up
+        t0 = time.perf_counter()
+        out = m.model(inputs_embeds=x).last_hidden_state
+        out.sum().backward()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best
+
+
+def _port_vs_reference(out):
+    """Calibration of the numpy port against the REFERENCE's own modules (torch CPU fp32, oracle/calibrate_cpu_baseline.py).  The reference
+    cannot be on this box during a driver run; round 4 measured the ratio ON A GPU NODE's own host cores once (staged scratch copy,
+    tools/stage_reference_loop.sh stage-models -> profiles/r04_cpu_baseline_calibration_gpu_node.json); the build container's 8-thread
+    figure (profiles/r03_cpu_baseline_calibration.json) is the fallback.  The ratio is a committed constant, NOT measured in this run:
+    its provenance (host threads of the calibration run vs the threads used now) is written next to it."""
+    for name, where in (("r04_cpu_baseline_calibration_gpu_node.json", "a GPU node of this pool"), ("r03_cpu_baseline_calibration.json", "the build container")):
+        cal = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(cal):
+            continue
+        with open(cal) as f:
+            c = json.load(f)
+        r = c["step_mix"]["port_vs_reference"]
+        out["port_vs_reference"] = round(r, 3)
+        out["reference_equivalent_value"] = round(out["value"] / r, 5)
+        out["calibration"] = ("the reference's own modules (gated block, 6-layer perceiver, MPT block; fwd+bwd, fp32, torch CPU) ran the same sample in "
+                              "%.2fx the time of the numpy port on %s: reference-equivalent rate = value / port_vs_reference" % (r, where))
+        out["calibration_provenance"] = {"file": "profiles/" + name, "measured_in_this_run": False, "calibration_host_threads": c.get("host_threads"),
+                                         "calibration_host_logical_cpus": c.get("cpu_count"), "threads_used_now": out["cores"],
+                                         "logical_cpus_now": os.cpu_count()}
+        break
+    return out
+
+
+def cpu_baseline(T=512, config="c2"):
+    """Oracle (numpy port) timed per component on one pair, extrapolated to the whole step by component counts.  config "c4": the
+    8-frame video pair of BASELINE configs[3] -- perceiver over 2048 patch features, 8 CLIP passes, and the LLaMA-7B host timed through
+    transformers' own LlamaForCausalLM layer (the class the reference instantiates)."""
     from oracle import otter_oracle as O
     from oracle import synth
 
-    D, Dv, V = 4096, 1024, 50432
+    D, Dv = 4096, 1024
+    V = 50432 if config == "c2" else 32004
+    frames = 1 if config == "c2" else 8
     r = np.random.default_rng(0)
 
     def rnd(*s, scale=0.02):
@@ -243,18 +382,22 @@ def cpu_baseline(T=512):
     O.gated_xattn_block_bwd(p, "b.", y, c)
     t["gated_block"] = time.perf_counter() - t0
     del p, c
-    # frozen MPT block, fwd + dgrad
-    p = {k: rnd(*s) if len(s) == 2 else np.ones(s, np.float32) for k, s in synth.mpt_block_shapes("m.", D).items()}
-    bias = O.mpt_attn_bias(32, T, 2048)
-    t0 = time.perf_counter()
-    y, c, _ = O.mpt_block_fwd(p, "m.", x, 32, bias)
-    O.mpt_block_bwd_input(p, "m.", y, c)
-    t["mpt_block"] = time.perf_counter() - t0
-    del p, c
-    # perceiver resampler (6 layers), 1 image, fwd + bwd
+    # frozen decoder block, fwd + dgrad
+    if config == "c2":
+        p = {k: rnd(*s) if len(s) == 2 else np.ones(s, np.float32) for k, s in synth.mpt_block_shapes("m.", D).items()}
+        bias = O.mpt_attn_bias(32, T, 2048)
+        t0 = time.perf_counter()
+        y, c, _ = O.mpt_block_fwd(p, "m.", x, 32, bias)
+        O.mpt_block_bwd_input(p, "m.", y, c)
+        t["lm_block"] = time.perf_counter() - t0
+        del p, c
+    else:
+        t["lm_block"] = _hf_decoder_layer_seconds("llama", T, train_all=False)
+    # perceiver resampler (6 layers), 1 image / 1 eight-frame video, fwd + bwd
+    extra = dict(max_num_frames=8) if frames > 1 else {}
     p = {k: rnd(*s) if len(s) == 2 and min(s) > 64 else np.ones(s, np.float32) * 0.5
-         for k, s in synth.perceiver_shapes("p.", Dv, 6).items()}
-    feats = rnd(1, 1, 1, 256, Dv, scale=1.0)
+         for k, s in synth.perceiver_shapes("p.", Dv, 6, **extra).items()}
+    feats = rnd(1, 1, frames, 256, Dv, scale=1.0)
     t0 = time.perf_counter()
     y, c = O.perceiver_resampler_fwd(p, "p.", feats)
     O.perceiver_resampler_bwd(p, "p.", y, c)
@@ -267,39 +410,54 @@ def cpu_baseline(T=512):
     O.clip_vision_fwd(cp, "v.", pix, 16, 14)
     t["clip_layer"] = time.perf_counter() - t0
     del cp
-    # tied un-embedding + CE: logits fwd, dX and dW bwd on 512 tokens
+    # un-embedding + CE: logits fwd, dX (and dW where the matrix trains: the tied MPT embedding; LLaMA's lm_head is frozen) bwd on 512 tokens
     W = rnd(V, D)
     h = rnd(T, D, scale=1.0)
     t0 = time.perf_counter()
     logits = h @ W.T
     _, dl = O.cross_entropy_rolled(logits[None], r.integers(0, V, size=(1, T)))
     _ = dl[0] @ W
-    _ = dl[0].T @ h
+    if config == "c2":
+        _ = dl[0].T @ h
     t["unembed_loss"] = time.perf_counter() - t0
-    per_pair = 8 * t["gated_block"] + 32 * t["mpt_block"] + t["perceiver"] + 24 * t["clip_layer"] + t["unembed_loss"]
-    sample = ("numpy oracle, fp32, 1 pair (1x224^2 image + 512 tokens): timed 1 gated-xattn block fwd+bwd (%.2fs), 1 MPT block "
+    per_pair = 8 * t["gated_block"] + 32 * t["lm_block"] + t["perceiver"] + 24 * frames * t["clip_layer"] + t["unembed_loss"]
+    lm = "MPT block (numpy oracle)" if config == "c2" else "LLaMA-7B layer (transformers' LlamaForCausalLM, torch CPU fp32 -- the class the reference instantiates)"
+    sample = ("numpy oracle, fp32, 1 pair (%dx224^2 image + %d tokens): timed 1 gated-xattn block fwd+bwd (%.2fs), 1 %s "
               "fwd+dgrad (%.2fs), 6-layer perceiver fwd+bwd (%.2fs), 1 CLIP layer fwd (%.2fs), unembed+CE fwd+bwd (%.2fs); step "
-              "time = 8*gated + 32*mpt + perceiver + 24*clip + unembed (optimizer/all-reduce not included)"
-              % (t["gated_block"], t["mpt_block"], t["perceiver"], t["clip_layer"], t["unembed_loss"]))
-    out = {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": os.cpu_count(), "kind": "port", "sample": sample}
-    # calibration of the numpy port against the REFERENCE's own modules (torch CPU fp32, oracle/calibrate_cpu_baseline.py).  The reference
-    # cannot be on this box during a driver run; round 4 measured the ratio ON A GPU NODE's own host cores once (staged scratch copy,
-    # tools/stage_reference_loop.sh stage-models -> profiles/r04_cpu_baseline_calibration_gpu_node.json); the build container's 8-thread
-    # figure (profiles/r03_cpu_baseline_calibration.json) is the fallback.
-    for name, where in (("r04_cpu_baseline_calibration_gpu_node.json", "a GPU node of this pool (%d host threads)"), ("r03_cpu_baseline_calibration.json", "the build container (%d threads)")):
-        cal = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(cal):
-            continue
-        with open(cal) as f:
-            c = json.load(f)
-        r = c["step_mix"]["port_vs_reference"]
-        out["port_vs_reference"] = round(r, 3)
-        out["reference_equivalent_value"] = round(out["value"] / r, 5)
-        out["calibration"] = ("the reference's own modules (gated block, 6-layer perceiver, MPT block; fwd+bwd, fp32, torch CPU) run the same sample in "
-                              "%.2fx the time of the numpy port on %s: reference-equivalent rate = value / port_vs_reference"
-                              % (r, where % c["host_threads"]))
-        break
-    return out
+              "time = 8*gated + 32*lm + perceiver + %d*clip + unembed (optimizer/all-reduce not included)"
+              % (frames, T, t["gated_block"], lm, t["lm_block"], t["perceiver"], t["clip_layer"], t["unembed_loss"], 24 * frames))
+    out = {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": _blas_threads(), "host_logical_cpus": os.cpu_count(), "kind": "port", "sample": sample}
+    return _port_vs_reference(out)
+
+
+def cpu_baseline_c5(B, S, text):
+    """C5 (OtterHD / Fuyu-8B, every parameter trains): one Persimmon layer at full width through transformers' PersimmonForCausalLM on the
+    host cores (fwd + full bwd, one sample of S positions), the 2700 -> 4096 patch projection and the 262144-row un-embedding + CE in numpy;
+    step = layers * layer + projection + unembed (the optimizer sweep over 9.4 B parameters is not included)."""
+    from oracle import otter_oracle as O
+
+    L, V, D = text["num_hidden_layers"], text["vocab_size"], text["hidden_size"]
+    r = np.random.default_rng(0)
+    t_layer = _hf_decoder_layer_seconds("persimmon", S, train_all=True)
+    Wp = r.standard_normal((D, 2700), dtype=np.float32) * 0.02
+    patches = r.standard_normal((1296, 2700), dtype=np.float32)
+    t0 = time.perf_counter()
+    e = patches @ Wp.T
+    _ = e.T @ patches
+    t_proj = time.perf_counter() - t0
+    W = r.standard_normal((V, D), dtype=np.float32) * 0.02
+    h = r.standard_normal((S, D), dtype=np.float32)
+    t0 = time.perf_counter()
+    logits = h @ W.T
+    _, dl = O.cross_entropy_rolled(logits[None], r.integers(0, V, size=(1, S)))
+    _ = dl[0] @ W
+    _ = dl[0].T @ h
+    t_un = time.perf_counter() - t0
+    per_pair = L * t_layer + t_proj + t_un
+    return {"value": round(1.0 / per_pair, 5), "unit": "pairs/s", "cores": _blas_threads(), "host_logical_cpus": os.cpu_count(), "kind": "port",
+            "sample": ("fp32, 1 pair (%d positions): 1 Persimmon layer fwd+bwd through transformers' PersimmonForCausalLM on torch CPU (%.2fs; the class the "
+                       "reference's fuyu/modeling_persimmon.py restates), patch projection fwd+wgrad in numpy (%.2fs), un-embedding + CE fwd+bwd in numpy "
+                       "(%.2fs); step time = %d*layer + projection + unembed (optimizer/all-reduce not included)" % (S, t_layer, t_proj, t_un, L))}
 
 
 def gated_block_roofline(model, batch, B, T, device, iters=20):
@@ -495,13 +653,18 @@ def main():
             v = args.gemm_variant or 26
             names = {13: "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves, phased)", 18: "gemm_bf16_r4_kernel (256x256x64 tile, 4 waves, register-resident K-tile)",
                      26: "gemm_bf16_t4_kernel (256x256x64 tile, 4 waves, register-resident K-tile, 16x16x32 MFMA)"}
-            pmc = os.path.join(ROOT, "profiles", {18: "r02_pmc_gemm_ffn_v18.json", 26: "r03_pmc_gemm_ffn_traffic.json"}.get(v, "r01_pmc_gemm_ffn_v13.json"))
-            if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
-                with open(pmc) as f:
-                    traffic = json.load(f).get("traffic_bytes_per_launch")
+            traffic_src = None
+            for cand in ({18: ["r02_pmc_gemm_ffn_v18.json"], 26: ["r05_pmc_gemm_ffn_traffic.json", "r03_pmc_gemm_ffn_traffic.json"]}.get(v, ["r01_pmc_gemm_ffn_v13.json"])):
+                pmc = os.path.join(ROOT, "profiles", cand)          # newest committed PMC pass of this kernel first
+                if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
+                    with open(pmc) as f:
+                        traffic = json.load(f).get("traffic_bytes_per_launch")
+                    traffic_src = "profiles/" + cand
+                    break
             roof = {"bound": "mfma", "kernel": "%s M=%d N=%d K=%d" % (names.get(v, "gemm variant %d" % v), M, N, Kd), "achieved": round(ach, 1),
                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "launches": n_launch, "avg_us": round(avg_s * 1e6, 1)}
+                    "launches": n_launch, "avg_us": round(avg_s * 1e6, 1), "traffic_source": traffic_src,
+                    "algorithmic_bytes": 2 * (M * Kd + N * Kd + M * N)}
             # the same kernel runs in two operand layouts: K-contiguous rows (forward products) and K-major (round 3: the backward
             # products read their operands in place through transpose reads); both are in `achieved`, split here
             if n_km and n_launch > n_km:
@@ -532,8 +695,10 @@ def main():
             "loss": round(float(loss), 4),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == "c2":
-            out["cpu_baseline"] = cpu_baseline(T)
+        if world == 1 and not n_occ:
+            apply_calibration(out, roof, machine_calibration(device))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(T, args.config)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

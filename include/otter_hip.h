@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define OTTER_ABI_VERSION 2   /* bump on ANY change of an exported signature or struct layout (otter_amd/_capi.py reads this line) */
+#define OTTER_ABI_VERSION 3   /* bump on ANY change of an exported signature or struct layout (otter_amd/_capi.py reads this line) */
 
 typedef enum { OTTER_F32 = 0, OTTER_BF16 = 1 } otter_dtype;
 
@@ -414,6 +414,13 @@ int otter_prof_collect_split(int* count, double* total_ms, int* count_kmajor, do
 /* Diagnostics (bench.py OTTER_BENCH_OCCUPY_CUS): n workgroups that each pin one CU's whole LDS and sleep until *flag
  * (device memory) becomes non-zero or max_ticks of the 100 MHz wall clock pass -- stands in for a communication kernel's hold on CUs. */
 int otter_debug_occupy_cus(int n_workgroups, int* flag, unsigned long long max_ticks, void* stream);
+
+/* Machine calibration for bench.py's `roofline` object (round 5; nothing in the reference to replace -- SURVEY.md 8d asks the builder to
+ * "confirm with a microbenchmark and report measured peaks"): n_workgroups x 4 waves issue `iters` x 64 back-to-back
+ * v_mfma_f32_16x16x32_bf16 (the product GEMM's instruction; 1 048 576 FLOP per wave and iteration) on the caller's operand bits
+ * (`operands`: 1 MiB, read once).  out: uint64[2 * n_workgroups (+ slack: allocate 2 * n_workgroups + 256 * n_workgroups)]:
+ * [2b] = shader-clock cycles (s_memtime), [2b + 1] = 100 MHz wall-clock ticks (s_memrealtime) of workgroup b's loop. */
+int otter_probe_mfma(const void* operands, void* out, int iters, int n_workgroups, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ def _declared_abi_version() -> int:
     return int(m.group(1))
 
 
-ABI_VERSION_MIRROR = 2
+ABI_VERSION_MIRROR = 3
 ABI_VERSION = _declared_abi_version()
 F32, BF16 = 0, 1
 GRID_DEFAULT, GRID_PERSISTENT, GRID_PER_TILE = 0, 1, 2    # otter_grid_mode
@@ -87,6 +87,7 @@ SIGNATURES = {
     "otter_last_error": (C.c_char_p, []),
     "otter_device_check": (_int, []),
     "otter_debug_occupy_cus": (_int, [_int, _vp, C.c_ulonglong, _vp]),
+    "otter_probe_mfma": (_int, [_vp, _vp, _int, _int, _vp]),
     "otter_layernorm_fwd": (_int, [_vp, _int, _vp, _vp, _int, _vp, _int, RowMap, _vp, _vp, _vp, _i64, _i64, _f32, _vp]),
     "otter_add_layernorm_fwd": (_int, [_vp, _int, _vp, _int, _vp, _vp, _vp, _int, _vp, _int, _vp, _vp, _i64, _i64, _f32, _vp]),
     "otter_layernorm_bwd_workspace_bytes": (_i64, [_i64, _i64]),

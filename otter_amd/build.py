@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libotter_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "flash.hip", "optim.hip", "attn_mfma.hip", "loss.hip", "fuyu.hip", "decode.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "flash.hip", "optim.hip", "attn_mfma.hip", "loss.hip", "fuyu.hip", "decode.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result", "-Wno-unused-value"]
 # gemm.hip: the K-major instantiations of variant 26 keep their accumulators in explicit AGPRs behind asm MFMAs; hipcc must not use the
 # AGPR half as spill space of its own there (it would, between the K loop and the tail's read-back: measured as wrong blocks)

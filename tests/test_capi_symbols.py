@@ -33,7 +33,17 @@ def test_every_declared_symbol_is_exported(lib):
 
     for name in header_symbols():
         assert hasattr(lib, name), name
-    assert lib.otter_abi_version() == _capi.ABI_VERSION == 2
+    assert lib.otter_abi_version() == _capi.ABI_VERSION == _capi.ABI_VERSION_MIRROR == 3
+
+
+def test_abi_version_mirror_matches_header():
+    """_capi falls back to ABI_VERSION_MIRROR when the package is deployed without its sibling include/ directory."""
+    import re
+
+    from otter_amd import _capi
+
+    m = re.search(r"^#define\s+OTTER_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "otter_hip.h")).read(), re.M)
+    assert int(m.group(1)) == _capi.ABI_VERSION_MIRROR == _capi.ABI_VERSION
 
 
 def test_argument_validation_without_gpu(lib):
