@@ -230,7 +230,7 @@ def test_product_never_imports_the_oracle():
     for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and ("oracle" in ((getattr(n, "module", None) or "") + " ".join(a.name for a in n.names)))
                    for n in ast.walk(fn))
-        assert (not uses) or fn.name == "cpu_baseline", fn.name
+        assert (not uses) or fn.name in ("cpu_baseline", "cpu_baseline_c5"), fn.name      # the cpu_baseline leg (C2 / C4, and C5's), nothing else
 
 
 def test_mpt_mlp_cpu_path_is_the_reference_gelu():
