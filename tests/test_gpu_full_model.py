@@ -439,8 +439,13 @@ def test_bf16_production_mode_training_step_backward_and_adamw_vs_oracle(full):
         ids = np.unique(_train_batch(full)[1].cpu().numpy())
         wg = dict(model.named_parameters())[LP + "wte.weight"].grad
         out["wte_batch_rows_row_rel"] = G.row_rel_err(wg[torch.from_numpy(ids).to(DEV)].cpu().numpy(), ref["g"][LP + "wte.weight"][ids])
-        _check_adamw(full, step, snap, ref, out, tol_state=BF16_STATE_TOL, tol_delta=None)
-        G.record("full_model_train_step_bf16", **out, per_tensor={k: [float(x) for x in v] for k, v in rec.items() if any(k.startswith(LP + "blocks.%d." % i) for i in FULL_BLOCKS) or k.startswith("perceiver.la") or k.endswith("wte.weight")})
+        top = sorted(rec.items(), key=lambda kv: -kv[1][0])[:8]
+        print("[g1] bf16 train step: worst gradients (rel l2, rel max, cosine):", [(k, ["%.2e" % x for x in v]) for k, v in top], flush=True)
+        G.record("full_model_train_step_bf16_gradients", **out, per_tensor={k: [float(x) for x in v] for k, v in rec.items() if any(k.startswith(LP + "blocks.%d." % i) for i in FULL_BLOCKS) or k.startswith("perceiver.la") or k.endswith("wte.weight")})
+        try:
+            _check_adamw(full, step, snap, ref, out, tol_state=BF16_STATE_TOL, tol_delta=None)
+        finally:
+            G.record("full_model_train_step_bf16", **out)
         assert abs(loss - ref["loss"]) <= BF16_LOSS_TOL * abs(ref["loss"]), (loss, ref["loss"])
         for n, (l2, mx, cs) in rec.items():
             assert l2 < BF16_GRAD_L2_TOL and cs > BF16_GRAD_COS_MIN, (n, l2, cs)
