@@ -130,7 +130,11 @@ def build_model(device, seed=0, debug_layers=0, config="c2", frozen_dtype=torch.
     g = torch.Generator(device=device).manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
-            if p.ndim >= 2:
+            # (the resampler's learned latents / frame / media-time embeddings keep the reference's own initialisation, torch.randn --
+            # modeling_otter.py:202-205: at N(0, 0.02) the 64 latents come out of the random-init resampler nearly identical, every
+            # cross-attention row is then a softmax over 64 copies of one key, and the query-side gradients become a difference of
+            # near-equal bf16 numbers -- ill-conditioned for the reference under bf16 autocast just the same)
+            if p.ndim >= 2 and name.rsplit(".", 1)[-1] not in ("latents", "frame_embs", "media_time_embs"):
                 p.normal_(0.0, 0.02, generator=g)
             if name.endswith("attn_gate") or name.endswith("ff_gate"):
                 p.fill_(0.5)  # zero-init gates make the block an identity (modeling_otter.py:362,371)
