@@ -175,7 +175,7 @@ def run_c5(args, device, rank, world, use_dist):
     params = [p for p in model.parameters()]
     opt = FusedAdamW([{"params": [p for p in params if p.ndim >= 2], "weight_decay": 0.1}, {"params": [p for p in params if p.ndim < 2], "weight_decay": 0.0}],
                      lr=1e-5, max_grad_norm=1.0)
-    reducer = GradReducer(params, 1 << 30) if use_dist else None
+    reducer = GradReducer(params, 1 << 30, overlap=args.dp_overlap == "on") if use_dist else None
     B, text_len = args.batch, 64
     grid, P = 36, 36 * 36
     S = grid * (grid + 1) + text_len                      # 1332 image positions (36 rows x (36 patches + newline)) + text
@@ -529,7 +529,15 @@ def main():
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--flash-variant", type=int, default=0, help="A/B hook: otter_flash_set_variant (2 = plain grid order instead of longest-first)")
     ap.add_argument("--debug-layers", type=int, default=0, help="DEBUG ONLY: shrink MPT to this many layers (not a valid bench)")
+    ap.add_argument("--dp-overlap", choices=["on", "off"], default="on",
+                    help="N > 1: launch each gradient bucket's RCCL all-reduce from its last gradient's hook, overlapped with the frozen decoder's "
+                         "backward (on, the default), or reduce every bucket after backward (off) -- the A/B a multi-GPU session needs (echoed in config)")
+    ap.add_argument("--rccl-max-channels", type=int, default=0,
+                    help="N > 1: cap RCCL's channel count (NCCL_MAX_NCHANNELS, set before the process group is created): fewer channels = fewer CUs held "
+                         "by a resident collective while the backward GEMMs run (0 = RCCL's default; echoed in config)")
     args = ap.parse_args()
+    if args.rccl_max_channels > 0:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_channels)     # read by RCCL at communicator creation (inherited by spawned ranks)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the ranks ourselves (one process per GPU), exactly the launch the driver uses
@@ -582,7 +590,7 @@ def main():
         ops.set_flash_variant(args.flash_variant)
     model = build_model(device, seed=0, debug_layers=args.debug_layers, config=args.config)  # identical replica on every rank (same seed)
     step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16,
-                     force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1")
+                     force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1", dp_overlap=args.dp_overlap == "on")
     B, T = args.batch, args.seq
     from otter_amd.train import masking
 
@@ -695,7 +703,10 @@ def main():
                                      "batch %d per GPU (BASELINE configs[1]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B)) if args.config == "c2" else
                                     ("OTTER-Video-LLaMA7B-DenseCaption train step, 8x224^2 frames (T_img=1, F=8: 2048 patches) + %d tokens per pair, "
                                      "batch %d per GPU (BASELINE configs[3]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B))),
-                       "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world},
+                       "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
+                       "dp_overlap": args.dp_overlap if use_dist else None,
+                       "rccl_max_channels": (args.rccl_max_channels or os.environ.get("NCCL_MAX_NCHANNELS")) if use_dist else None,
+                       "gemm_grid": "per-tile" if step.grid_mode == 2 else "persistent"},
             "loss": round(float(loss), 4),
             "roofline": roof,
         }

@@ -780,127 +780,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(GemmArgs g) {
     }  // persistent tile loop
 }
 
-#ifdef OTTER_EXPERIMENTAL  // tools-only variant (python -m otter_amd.build --experimental)
-// ------------------------------------------------------------------------------------------------------------
-// bf16 wave-specialised kernel (variant 8): 8 MFMA waves + 4 LOADER waves (768 threads, 3 waves per SIMD).
-// Why: ablations with a diagnostics build (tools/gemm_load_exp.py) showed that in every schedule above the LDS-DMA stream
-// and the MFMA stream do not overlap -- MFMAs on register-resident fragments (no LDS reads) + DMA take the SUM of the two
-// (447 us vs 273 + 278 - 56), at an unthrottled 2.38 GHz.  A wave issues in order: once the CU's vector-memory queue is
-// full, a wave that still has global_load_lds instructions to issue sits on them until the queue drains (64 KB per K-tile
-// = ~0.86 us per CU, the same as the MFMA time of the tile), and cannot issue its MFMAs meanwhile.  So the DMA is issued
-// by waves that have nothing else to do: waves 8-11 (one per SIMD) each fetch 16 of the 64 1-KB pieces of the [A ; B]
-// K-tile into the buffer the MFMA waves will read next, wait for their own vmcnt and meet the others at the per-tile
-// barrier; waves 0-7 never touch vector memory inside the K loop (fragment reads + MFMAs only, 2 per SIMD).  One loader
-// is not enough: measured 3.9 us per K-tile with a single loader wave (~17 GB/s of LDS-DMA per wave).
-// Register budget: 12 waves -> 3 per SIMD -> <= 168 VGPRs per wave for the whole kernel.
-// ------------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(768) void gemm_bf16_ws_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, WN = 4;
-    constexpr int TM = 128, TN = 64, MI = 4, NI = 2;
-    constexpr int TILE_BYTES = (BM + BN) * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= 8;   // waves 8..11: one loader per SIMD (a single wave sustains only ~17-25 GB/s of LDS-DMA)
-    const int lw = wave & 3;
-    const int wm = (wave & 7) / WN, wn = (wave & 7) % WN;
-    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
-    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
-    const int nk = (int)(g.K >> 6);
-    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
-    const int ntiles = g.gm * g.gn;
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-        int tile_m, tile_n;
-        tile_of_block(g, vb, tile_m, tile_n);
-        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-
-        // ---- loader: piece j (0..63) = rows 8j..8j+7 of the stacked [A rows ; B rows] tile, 1 KB, lane -> (row, slot) ----
-        const int lrow = lane >> 3, phys = lane & 7;
-        auto fetch_tile = [&](int buf, int kt) {
-            const int64_t koff = (int64_t)kt * 64;
-#pragma unroll 4
-            for (int jj = 0; jj < 16; ++jj) {
-                const int j = lw * 16 + jj;                        // loader lw fetches pieces 16*lw .. 16*lw+15
-                const int row = (j & 31) * 8 + lrow;               // row inside the operand tile
-                const int slot = phys ^ ((row >> 1) & 7);
-                const bf16_t* src;
-                if (j < 32) {
-                    int64_t gr = m0 + row; if (gr > g.M - 1) gr = g.M - 1;
-                    src = A + gr * g.lda + koff + slot * 8;
-                } else {
-                    int64_t gr = n0 + row; if (gr > g.N - 1) gr = g.N - 1;
-                    src = B + gr * g.ldb + koff + slot * 8;
-                }
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(smem + buf * TILE_BYTES + j * 1024), 16, 0, 0);
-            }
-        };
-
-        if (loader) {
-            // ---- loader wave: no accumulators live anywhere on this path; same barrier sequence as the MFMA waves ----
-            fetch_tile(0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            for (int t = 0; t < nk; ++t) {
-                if (t + 1 < nk) fetch_tile((t & 1) ^ 1, t + 1);   // that buffer was released by the barrier that ended step t-1
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-            block_partial<8, EPI>(g, 0.f, reinterpret_cast<float*>(smem), vb);
-            __syncthreads();
-        } else {
-            f32x16_t acc[MI][NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-            __syncthreads();
-            for (int t = 0; t < nk; ++t) {
-                const char* At = smem + (t & 1) * TILE_BYTES;
-                const char* Bt = At + BM * 128;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int slot = 2 * ks + (lane >> 5);
-                    bf16x8_t fa[NI], fb[MI];
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const int row = wn * TN + ni * 32 + (lane & 31);
-                        fa[ni] = *reinterpret_cast<const bf16x8_t*>(Bt + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const int row = wm * TM + mi * 32 + (lane & 31);
-                        fb[mi] = *reinterpret_cast<const bf16x8_t*>(At + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ni], fb[mi], acc[mi][ni], 0, 0, 0);
-                }
-                __syncthreads();
-            }
-            // ---- epilogue: wave-private LDS stripes ----
-            float part = 0.f;
-            float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) park_block(blk, acc[mi][ni], lane, ni * 32);
-                __builtin_amdgcn_wave_barrier();
-                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * TM + mi * 32, n0 + wn * TN, lane);
-                __builtin_amdgcn_wave_barrier();
-            }
-            block_partial<8, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
-            __syncthreads();
-        }
-    }
-}
-
-#endif  // OTTER_EXPERIMENTAL (variant 8)
+#ifdef OTTER_EXPERIMENTAL  // tools-only: variant 8: wave-specialised kernel (8 MFMA waves + 4 loader waves)
+#include "experimental/gemm_ws_variant8.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // bf16 phased kernel (variant 6): the 256x256x64 / 8-wave / LDS-DMA kernel above with the K-tile split into four
@@ -1375,994 +1257,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_ph_kernel(GemmArgs g) {
 #undef RAW_BARRIER
 }
 
-#ifdef OTTER_EXPERIMENTAL  // tools-only variants (python -m otter_amd.build --experimental): the round-1/2 kernel generations that led to variant 26
-// ------------------------------------------------------------------------------------------------------------
-// bf16 multi-stage kernel (variant 4): 256x256 tile, 4 waves = ONE wave per SIMD, each wave owns 128x128 (4x4 blocks of
-// 32x32 -> 256 accumulator registers, the other half of the 512-entry unified file holds operands), K advanced in
-// steps of 32 through an NS-deep LDS ring filled by global_load_lds_dwordx4.
-//   * larger wave tile: 8 ds_read_b128 per 16 MFMAs (vs 12 in the 8-wave kernel) -> 1/3 less LDS read traffic, which
-//     competes with the LDS-DMA writes for the same LDS port;
-//   * ring depth NS (4 or 5): the DMA of step s+NS-1 is issued at the start of step s, so a load has NS-2 whole steps
-//     to land instead of one K-tile -- the exposed tail of the 2-buffer schedule (latency + burst time of 256 CUs
-//     fetching 64 KB each at once) is what the ablation showed to be un-overlapped;
-//   * "lagged" visibility: the wait that retires step s+2's DMA sits before barrier B(s+1), so after any barrier the
-//     current AND the next step's stages are readable: the first fragments of step s+1 are fetched during the last MFMAs
-//     of step s and the MFMA stream continues straight through the barrier;
-//   * counted s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads() would drain the DMA queue: guide section 5).
-// LDS image per stage: [256 A rows ; 256 B rows] x 64 B; 16-B slot index XOR (row>>2)&3 (four rows share a 256-B bank
-// row): a ds_read_b128 lane group (16 rows, one logical slot) covers 16 distinct 16-B positions -> conflict-free.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int MS_EPI_LD = 132;  // 128 + 4 floats
-
-template <int EPI>
-__device__ __forceinline__ float epilogue_stripe128(const GemmArgs& g, float s, const float* __restrict__ blk, int64_t m_base,
-                                                    int64_t n_base, int lane) {
-    float part = 0.f;
-#pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-        const int r = (lane >> 5) + 2 * it;
-        const int c = (lane & 31) * 4;
-        const int64_t m = m_base + r, n = n_base + c;
-        if (m < g.M && n < g.N) {
-            const float4 t = *reinterpret_cast<const float4*>(blk + r * MS_EPI_LD + c);
-            float v[4] = {t.x, t.y, t.z, t.w};
-            part += epilogue4<EPI>(g, s, m, n, v);
-        }
-    }
-    return part;
-}
-
-template <int NS, int EPI, bool BUF>
-__global__ __launch_bounds__(256) void gemm_bf16_ms_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, BK = 32, NT = 256;
-    constexpr int STAGE = (BM + BN) * BK * 2;  // 32 KB
-    constexpr int CH = BM * 4 / NT;            // 16-B chunks per thread per operand per stage = 4
-    constexpr int PD = NS - 1;                 // prefetch distance in steps
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int tile_m, tile_n;
-    tile_of_block(g, (int)blockIdx.x, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
-    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
-    const int nk = (int)(g.K >> 5);
-
-    const bf16_t* pa[CH];
-    const bf16_t* pb[CH];
-    uint32_t oa[CH], ob[CH];  // BUF: 32-bit byte offsets against SGPR buffer descriptors
-    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
-    if constexpr (BUF) {
-        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
-        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
-    }
-#pragma unroll
-    for (int i = 0; i < CH; ++i) {
-        const int c = i * NT + tid, row = c >> 2, phys = c & 3;
-        const int slot = phys ^ ((row >> 2) & 3);
-        int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
-        int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
-        pa[i] = A + ga * g.lda + slot * 8;
-        pb[i] = B + gb * g.ldb + slot * 8;
-        oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
-        ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
-    }
-    auto issue_a = [&](int step) {
-        const int buf = step % NS;
-        const int64_t koff = (int64_t)step * BK;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int wbase = buf * STAGE + (i * NT + wave * 64) * 16;
-            if constexpr (BUF)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
-                                                         (int)oa[i], step * (BK * 2), 0, 0);
-            else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
-        }
-    };
-    auto issue_b = [&](int step) {
-        const int buf = step % NS;
-        const int64_t koff = (int64_t)step * BK;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int wbase = buf * STAGE + BM * 64 + (i * NT + wave * 64) * 16;
-            if constexpr (BUF)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16,
-                                                         (int)ob[i], step * (BK * 2), 0, 0);
-            else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(smem + wbase), 16, 0, 0);
-        }
-    };
-    auto issue = [&](int step) {
-        issue_a(step);
-        issue_b(step);
-    };
-    // per-lane fragment offsets inside a stage (row part; the k-slot part is added per k-step)
-    int offA[4], offB[4], swzA[4], swzB[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = wm * 128 + i * 32 + (lane & 31);
-        const int rb = wn * 128 + i * 32 + (lane & 31);
-        offA[i] = ra * 64; swzA[i] = (ra >> 2) & 3;
-        offB[i] = BM * 64 + rb * 64; swzB[i] = (rb >> 2) & 3;
-    }
-    auto load_frags = [&](int step, int ks, bf16x8_t (&fm)[4], bf16x8_t (&fn)[4]) {
-        const char* base = smem + (step % NS) * STAGE;
-        const int slot = 2 * ks + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fm[i] = *reinterpret_cast<const bf16x8_t*>(base + offA[i] + ((slot ^ swzA[i]) << 4));
-            fn[i] = *reinterpret_cast<const bf16x8_t*>(base + offB[i] + ((slot ^ swzB[i]) << 4));
-        }
-    };
-
-    f32x16_t acc[4][4];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    // one quarter of a k-step: the 4 MFMAs of accumulator row mi (operands swapped: a = B rows, b = A rows)
-    auto mma_q = [&](const bf16x8_t (&fm)[4], const bf16x8_t (&fn)[4], int mi) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[ni], fm[mi], acc[mi][ni], 0, 0, 0);
-    };
-    auto mma = [&](const bf16x8_t (&fm)[4], const bf16x8_t (&fn)[4]) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) mma_q(fm, fn, mi);
-    };
-
-    // ---- prologue: fill PD stages, make stages 0 and 1 visible ----
-#pragma unroll
-    for (int p = 0; p < PD; ++p)
-        if (p < nk) issue(p);
-    // stages 0,1 landed  <=>  at most the groups of stages 2..PD-1 outstanding
-    if (nk >= PD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 2) * 2 * CH) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    bf16x8_t fm0[4], fn0[4], fm1[4], fn1[4];
-    load_frags(0, 0, fm0, fn0);
-    int s = 0;
-    // steady state: branch-free body so that the compiler can count lgkmcnt (the 8 newest ds_reads stay in flight under
-    // the MFMAs that consume the 8 older ones) -- fragments of the next k-step / next stage are always one MFMA group ahead
-    // One wave per SIMD: nothing else can cover a stall, so inside a step every non-MFMA instruction is issued in the
-    // shadow of MFMAs that are already queued and every wait finds its data long landed:
-    //   Xq0 | ds_read Y | Xq1 | DMA A(s+PD) | Xq2 | DMA B(s+PD) | Xq3 | Yq0 | ds_read X' | Yq1 Yq2 Yq3 | vmcnt | barrier
-    // (X = fragments of k-step 0, fetched during the previous step; Y = k-step 1; X' = k-step 0 of the next stage).
-#define SB() __builtin_amdgcn_sched_barrier(0)
-    for (; s + PD < nk; ++s) {
-        mma_q(fm0, fn0, 0); SB();
-        load_frags(s, 1, fm1, fn1); SB();
-        mma_q(fm0, fn0, 1); SB();
-        issue_a(s + PD); SB();            // ring slot (s+PD)%NS == (s-1)%NS: every wave is past B(s), i.e. done with step s-1
-        mma_q(fm0, fn0, 2); SB();
-        issue_b(s + PD); SB();
-        mma_q(fm0, fn0, 3); SB();
-        mma_q(fm1, fn1, 0); SB();
-        load_frags(s + 1, 0, fm0, fn0); SB();   // stage s+1 is already visible (lagged wait below); in flight across the barrier
-        mma_q(fm1, fn1, 1);
-        mma_q(fm1, fn1, 2);
-        mma_q(fm1, fn1, 3); SB();
-        // retire the DMA of stage s+2 (must be visible after the next barrier); newer groups stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 2) * 2 * CH));
-        __builtin_amdgcn_s_barrier();
-    }
-#undef SB
-    for (; s < nk; ++s) {                 // drain: nothing left to issue
-        load_frags(s, 1, fm1, fn1);
-        mma(fm0, fn0);
-        if (s + 1 < nk) load_frags(s + 1, 0, fm0, fn0);
-        mma(fm1, fn1);
-        asm volatile("s_waitcnt vmcnt(0)");
-        __builtin_amdgcn_s_barrier();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue (LDS ring is free: every DMA retired, every wave past the last barrier) ----
-    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
-    float part = 0.f;
-    float* blk = reinterpret_cast<float*>(smem) + wave * (32 * MS_EPI_LD);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            float* row = blk + (lane & 31) * MS_EPI_LD + ni * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int grp = 0; grp < 4; ++grp)
-                *reinterpret_cast<float4*>(row + 8 * grp) =
-                    make_float4(acc[mi][ni][4 * grp + 0], acc[mi][ni][4 * grp + 1], acc[mi][ni][4 * grp + 2], acc[mi][ni][4 * grp + 3]);
-        }
-        __syncthreads();
-        part += epilogue_stripe128<EPI>(g, sgate, blk, m0 + wm * 128 + mi * 32, n0 + wn * 128, lane);
-        __syncthreads();
-    }
-    block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), (int)blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// bf16 slot-interleaved kernel (variant 17): the 4-wave geometry of the multi-stage kernel above (256x256 tile, ONE wave
-// per SIMD, 128x128 per wave = 256 accumulator registers, BK = 32 stages in a 4-deep LDS ring filled by
-// `buffer_load ... lds`), re-scheduled after reading the ISA hipcc produced for it: there the 8 ds_read_b128 of a k-step
-// and the 4+4 DMA pieces of a stage were issued as BURSTS between groups of four MFMAs, and the ring slot came out of a
-// run-time modulo (three s_mul_hi + s_mul per step).  A wave that is alone on its SIMD has nothing to cover a burst: one
-// LDS-DMA piece costs ~60-180 cycles of issue (MI355X guide, instruction constants), an MFMA occupies the pipe for 32,
-// so every piece issued behind another piece leaves the matrix pipe idle.  Here:
-//   * ONE filler per MFMA slot, pinned: slot j of a 32-MFMA step = MFMA j, then (j even) one ds_read_b128 or (j = 1 mod 4)
-//     one DMA piece -- 16 reads + 8 pieces over 32 MFMAs, never two memory instructions back to back;
-//   * the K loop is unrolled by the ring depth, so ring slots, LDS offsets and M0 values are compile-time constants
-//     (no modulo, no per-step VALU address arithmetic: 8 per-lane base registers serve every fragment read);
-//   * fragments are double-buffered in registers across the step boundary: X = k-step 0 of the stage (read during the
-//     second half of the PREVIOUS step), Y = k-step 1 (read during the first half); the MFMA order inside each half uses
-//     the fragments in the order they were requested, so the compiler's counted lgkmcnt never waits on a fresh read;
-//   * one raw s_barrier per step with a counted `s_waitcnt vmcnt(8)`: the 8 pieces of the newest stage stay in flight,
-//     a stage has two whole steps (~1 us) to land;  visibility invariant at the top of step s: stages s and s+1 readable;
-//   * WAR: the DMA of stage s+3 targets ring slot (s-1)%4, whose last reads (its k-step 1 fragments) were consumed by
-//     MFMAs of step s-1 before that step's barrier;
-//   * persistent over tiles (XCD-chunked 8x4 super-tile order), epilogue = the 32x64 wave-private stripes of the 8-wave
-//     kernels (whole-cache-line accesses of the fused tail).
-// Requires K % 128 == 0 (four stages per unrolled trip) and operands spanning < 4 GB (32-bit buffer offsets).
-// ------------------------------------------------------------------------------------------------------------
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_q4_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NT = 256, NS = 4;
-    constexpr int STAGE = (BM + BN) * 64;  // 32 KB: [256 A rows ; 256 B rows] x 64 B
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
-    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
-    const int nk = (int)(g.K >> 5);  // stages (host guarantees nk % 4 == 0, nk >= 4)
-    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
-    const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
-    // fragment read bases: row = w*128 + i*32 + (lane&31); 16-B slot (2*ks + (lane>>5)) ^ ((row>>2)&3); the swizzle term
-    // only depends on lane (every other row term is a multiple of 32), and k-step 1 is k-step 0 with slot bit 1 flipped
-    const int swz = ((lane & 31) >> 2) & 3;
-    const int slot0 = ((lane >> 5) ^ swz) << 4;
-    int ra[2], rb[2];    // [ks], ring slots 0/1 via immediates
-    ra[0] = (wm * 128 + (lane & 31)) * 64 + slot0;
-    ra[1] = ra[0] ^ 32;
-    rb[0] = BM * 64 + (wn * 128 + (lane & 31)) * 64 + slot0;
-    rb[1] = rb[0] ^ 32;
-    int ra_hi[2], rb_hi[2];  // ring slots 2/3: separate base registers (ds_read immediates are 16 bits)
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        ra_hi[k] = ra[k] + 2 * STAGE;
-        rb_hi[k] = rb[k] + 2 * STAGE;
-        asm volatile("" : "+v"(ra_hi[k]), "+v"(rb_hi[k]));  // keep them as registers (do not re-fold into base + 65536 + imm)
-    }
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#define LDF(dst, base_lo, base_hi, S, KS, I)                                                                              \
-    do {                                                                                                                  \
-        if constexpr ((OTTER_DIAG & 8) == 0)                                                                              \
-            dst = *reinterpret_cast<const bf16x8_t*>(smem + ((S) < 2 ? base_lo[KS] + (S) * STAGE : base_hi[KS] + ((S) - 2) * STAGE) + (I) * 2048); \
-    } while (0)
-
-    const int ntiles = g.gm * g.gn;
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-        int tile_m, tile_n;
-        tile_of_block(g, vb, tile_m, tile_n);
-        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-        uint32_t oa[4], ob[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = i * NT + tid, row = c >> 2, phys = c & 3;
-            const int slot = phys ^ ((row >> 2) & 3);
-            int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
-            int64_t gb = n0 + row; if (gb > g.N - 1) gb = g.N - 1;
-            oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
-            ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
-        }
-        // piece p (0..3 = A, 4..7 = B) of the stage holding K columns [step*32, +32) into ring slot S
-        auto dma = [&](int S, int step, int p) {
-            if constexpr ((OTTER_DIAG & 1) != 0) return;
-            const int wbase = S * STAGE + (p >> 2) * (BM * 64) + ((p & 3) * NT + wave * 64) * 16;
-            if (p < 4)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p & 3],
-                                                         step * 64, 0, 0);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 3],
-                                                         step * 64, 0, 0);
-        };
-        f32x16_t acc[4][4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-        // ---- prologue: stages 0..2 in flight, 0 and 1 readable ----
-#pragma unroll
-        for (int st = 0; st < 3; ++st)
-#pragma unroll
-            for (int p = 0; p < 8; ++p) dma(st, st, p);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // fragment registers: fm = A rows (b-operand), fn = B rows (a-operand); X = k-step 0, Y = k-step 1
-        bf16x8_t xm[4], xn[4], ym[4], yn[4];
-        if constexpr ((OTTER_DIAG & 8) != 0) {  // fragments without LDS reads: lane-dependent, non-zero
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xm[i] = xn[i] = ym[i] = yn[i] = __builtin_bit_cast(bf16x8_t, uint4{0x3f803f80u + (unsigned)lane, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u});
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            LDF(xn[i], rb, rb_hi, 0, 0, i);
-            LDF(xm[i], ra, ra_hi, 0, 0, i);
-        }
-        // MFMA order of a half step and the fragment each one needs first: fragments are requested in the order
-        // n0 m0 m1 n1 m2 m3 n2 n3, so MFMA j only depends on the first RDY[j] requests of its half
-        //   j:   0     1     2     3     4     5     6     7     8     9     10    11    12    13    14    15
-        //  (m,n) 0,0   1,0   0,1   1,1   2,0   2,1   3,0   3,1   0,2   1,2   2,2   3,2   0,3   1,3   2,3   3,3
-#define MMA(FM, FN, MI, NI)                                                                                               \
-    do {                                                                                                                  \
-        if constexpr ((OTTER_DIAG & 2) == 0) acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FN[NI], FM[MI], acc[MI][NI], 0, 0, 0); \
-    } while (0)
-        // one step on ring slot S: DMA = issue stage (step + 3) into slot (S + 3) % 4; NEXT = read next stage's k-step 0
-#define STEP(S, STEPV, DMA, NEXT, VMW)                                                                                    \
-    do {                                                                                                                  \
-        constexpr int SN = ((S) + 1) & 3, SD = ((S) + 3) & 3;                                                             \
-        /* first half: MFMAs on X, reads of Y (this stage, k-step 1), DMA pieces 0..3 */                                  \
-        MMA(xm, xn, 0, 0); SB(); LDF(yn[0], rb, rb_hi, S, 1, 0); SB();                                                          \
-        MMA(xm, xn, 1, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 0); SB();                                                        \
-        MMA(xm, xn, 0, 1); SB(); LDF(ym[0], ra, ra_hi, S, 1, 0); SB();                                                          \
-        MMA(xm, xn, 1, 1); SB();                                                                                          \
-        MMA(xm, xn, 2, 0); SB(); LDF(ym[1], ra, ra_hi, S, 1, 1); SB();                                                          \
-        MMA(xm, xn, 2, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 1); SB();                                                        \
-        MMA(xm, xn, 3, 0); SB(); LDF(yn[1], rb, rb_hi, S, 1, 1); SB();                                                          \
-        MMA(xm, xn, 3, 1); SB();                                                                                          \
-        MMA(xm, xn, 0, 2); SB(); LDF(ym[2], ra, ra_hi, S, 1, 2); SB();                                                          \
-        MMA(xm, xn, 1, 2); SB(); if (DMA) dma(SD, (STEPV) + 3, 2); SB();                                                        \
-        MMA(xm, xn, 2, 2); SB(); LDF(ym[3], ra, ra_hi, S, 1, 3); SB();                                                          \
-        MMA(xm, xn, 3, 2); SB();                                                                                          \
-        MMA(xm, xn, 0, 3); SB(); LDF(yn[2], rb, rb_hi, S, 1, 2); SB();                                                          \
-        MMA(xm, xn, 1, 3); SB(); if (DMA) dma(SD, (STEPV) + 3, 3); SB();                                                        \
-        MMA(xm, xn, 2, 3); SB(); LDF(yn[3], rb, rb_hi, S, 1, 3); SB();                                                          \
-        MMA(xm, xn, 3, 3); SB();                                                                                          \
-        /* second half: MFMAs on Y, reads of X' (next stage, k-step 0), DMA pieces 4..7 */                                \
-        MMA(ym, yn, 0, 0); SB(); if (NEXT) LDF(xn[0], rb, rb_hi, SN, 0, 0); SB();                                               \
-        MMA(ym, yn, 1, 0); SB(); if (DMA) dma(SD, (STEPV) + 3, 4); SB();                                                        \
-        MMA(ym, yn, 0, 1); SB(); if (NEXT) LDF(xm[0], ra, ra_hi, SN, 0, 0); SB();                                               \
-        MMA(ym, yn, 1, 1); SB();                                                                                          \
-        MMA(ym, yn, 2, 0); SB(); if (NEXT) LDF(xm[1], ra, ra_hi, SN, 0, 1); SB();                                               \
-        MMA(ym, yn, 2, 1); SB(); if (DMA) dma(SD, (STEPV) + 3, 5); SB();                                                        \
-        MMA(ym, yn, 3, 0); SB(); if (NEXT) LDF(xn[1], rb, rb_hi, SN, 0, 1); SB();                                               \
-        MMA(ym, yn, 3, 1); SB();                                                                                          \
-        MMA(ym, yn, 0, 2); SB(); if (NEXT) LDF(xm[2], ra, ra_hi, SN, 0, 2); SB();                                               \
-        MMA(ym, yn, 1, 2); SB(); if (DMA) dma(SD, (STEPV) + 3, 6); SB();                                                        \
-        MMA(ym, yn, 2, 2); SB(); if (NEXT) LDF(xm[3], ra, ra_hi, SN, 0, 3); SB();                                               \
-        MMA(ym, yn, 3, 2); SB();                                                                                          \
-        MMA(ym, yn, 0, 3); SB(); if (NEXT) LDF(xn[2], rb, rb_hi, SN, 0, 2); SB();                                               \
-        MMA(ym, yn, 1, 3); SB(); if (DMA) dma(SD, (STEPV) + 3, 7); SB();                                                        \
-        MMA(ym, yn, 2, 3); SB(); if (NEXT) LDF(xn[3], rb, rb_hi, SN, 0, 3); SB();                                               \
-        MMA(ym, yn, 3, 3); SB();                                                                                          \
-        asm volatile("s_waitcnt vmcnt(" #VMW ")" ::: "memory");                                                           \
-        __builtin_amdgcn_s_barrier();                                                                                     \
-        SB();                                                                                                             \
-    } while (0)
-        int s = 0;
-        for (; s + 4 < nk; s += 4) {   // full trips: every step issues its stage s+3
-            STEP(0, s, true, true, 8);
-            STEP(1, s + 1, true, true, 8);
-            STEP(2, s + 2, true, true, 8);
-            STEP(3, s + 3, true, true, 8);
-        }
-        // last trip: stage nk-1 is issued by its first step, then the queue drains (nothing newer stays in flight)
-        STEP(0, s, true, true, 8);
-        STEP(1, s + 1, false, true, 0);
-        STEP(2, s + 2, false, true, 0);
-        STEP(3, s + 3, false, false, 0);
-#undef STEP
-#undef MMA
-
-        // ---- epilogue: the ring is free (every DMA retired, every wave past the last barrier, every fragment read consumed) ----
-        float part = 0.f;
-        float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
-        // full in-bounds tile with the wide bf16 / 16-byte f32 access shapes -> unrolled double-buffered tail, else the generic one
-        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (OTTER_DIAG & (4 | 16)) == 0 &&
-                          (g.cdt == OTTER_F32 || g.wide);
-        if (full) {
-            float* blk2 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
-            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
-            else part = tail_wave_full<EPI, false>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
-        } else {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            if constexpr ((OTTER_DIAG & 16) != 0) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) part += acc[mi][ni][r];
-                continue;
-            }
-#pragma unroll
-            for (int np = 0; np < 2; ++np) {
-                park_block(blk, acc[mi][2 * np], lane, 0);
-                park_block(blk, acc[mi][2 * np + 1], lane, 32);
-                __builtin_amdgcn_wave_barrier();
-                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 128 + mi * 32, n0 + wn * 128 + np * 64, lane);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        }
-        if constexpr ((OTTER_DIAG & 20) != 0) {  // keep `part` (hence the accumulators) observable
-            if (part == 12345.678f) reinterpret_cast<float*>(g.C)[threadIdx.x] = part;
-        }
-        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
-        __syncthreads();  // the next tile's prologue DMA overwrites the stripes
-    }
-#undef LDF
-#undef SB
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// bf16 register-resident K-tile kernel (variant 18): variant 17's geometry and slot pinning with the LDS image of the
-// 8-wave kernels -- BK = 64, 128-B rows, two 64 KB buffers -- because the ablation of variant 17 (tools/gemm_ablate.py,
-// diag builds) priced its LDS-DMA stream at 88 us of a 513 us launch against 50 us for the 128-B-row kernels: a 64-B row is
-// half a cache line, so every DMA instruction touches 16 lines instead of 8 and every line is requested twice.
-// Two buffers give a one-tile prefetch distance unless a buffer can be refilled while its tile is still being multiplied:
-// a wave's fragments of a WHOLE K-tile are 128 registers (4 k-steps x (4 + 4) x 4), and with the accumulators in the
-// AGPR half of the file that fits -- so every wave pulls its K-tile into registers during the first 24 MFMA slots, one
-// barrier later the buffer is dead, and the DMA of K-tile t+2 goes into it for the rest of the iteration: prefetch
-// distance two K-tiles (every piece has > 1700 cycles to land) out of two buffers.  Schedule of one K-tile (64 MFMA
-// slots, at most one filler each) -- generated by tools/gen/gemm_r4_schedule.py, see its header.
-// Requires K % 128 == 0 and operands spanning < 4 GB.
-// ------------------------------------------------------------------------------------------------------------
-template <int EPI, int SCH, bool PF>
-__global__ __launch_bounds__(256) void gemm_bf16_r4_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, NT = 256;
-    constexpr int TILE = (BM + BN) * 128;  // 64 KB: [256 A rows ; 256 B rows] x 128 B
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const bf16_t* __restrict__ A = (const bf16_t*)g.A;
-    const bf16_t* __restrict__ B = (const bf16_t*)g.B;
-    const int nk = (int)(g.K >> 6);  // K-tiles (host guarantees nk even, nk >= 2)
-    const float sgate = g.gate ? tanhf(*g.gate) : 1.0f;
-    const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)(uint32_t)((g.M - 1) * g.lda * 2 + g.K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)(uint32_t)((g.N - 1) * g.ldb * 2 + g.K * 2), 0x00020000);
-    // fragment read bases per k-step: row = w*128 + i*32 + (lane&31), 16-B slot (2*ks + (lane>>5)) ^ ((row>>1)&7); the
-    // swizzle term only depends on lane; buffer 1 (+64 KB) is out of reach of the 16-bit ds_read immediate -> own registers
-    const int swz = ((lane & 31) >> 1) & 7;
-    int ra[4], rb[4], ra_hi[4], rb_hi[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int slot = (2 * ks + (lane >> 5)) ^ swz;
-        ra[ks] = (wm * 128 + (lane & 31)) * 128 + (slot << 4);
-        rb[ks] = BM * 128 + (wn * 128 + (lane & 31)) * 128 + (slot << 4);
-        ra_hi[ks] = ra[ks] + TILE;
-        rb_hi[ks] = rb[ks] + TILE;
-        asm volatile("" : "+v"(ra_hi[ks]), "+v"(rb_hi[ks]));
-    }
-#define TMARK(K_)                                                                                                         \
-    do {                                                                                                                  \
-        if ((g.dbg & 64) && (blockIdx.x == 0 || blockIdx.x == 131) && lane == 0 && tcount < 8)                            \
-            g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + (K_)] = __builtin_amdgcn_s_memtime();  \
-    } while (0)
-    int tcount = 0;
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#define LDF(dst, base_lo, base_hi, BUFV, KS, I)                                                                           \
-    do {                                                                                                                  \
-        if constexpr ((OTTER_DIAG & 8) == 0)                                                                              \
-            dst = *reinterpret_cast<const bf16x8_t*>(smem + (((BUFV) & 1) ? base_hi[KS] : base_lo[KS]) + (I) * 4096);      \
-    } while (0)
-
-    const int ntiles = g.gm * g.gn;
-    // PF (variant 21): the DMA of the NEXT tile's first K-tile is issued before the current tile's tail (both buffers are dead once
-    // a wave leaves the K loop: every wave has passed barrier #1 of the last K-tile); the tail then parks in the second buffer
-    // (two stripes per phase) and the first buffer fills under it.  Counted vmcnt stays valid with the tail's stores in flight:
-    // loads retire in order among themselves, `vmcnt(16)` after the 16 pieces of K-tile 1 covers everything older.
-    uint32_t oa[8], ob[8];
-    auto set_offsets = [&](int64_t m0_, int64_t n0_) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = i * NT + tid, row = c >> 3, phys = c & 7;
-            const int slot = phys ^ ((row >> 1) & 7);
-            int64_t ga = m0_ + row; if (ga > g.M - 1) ga = g.M - 1;
-            int64_t gb = n0_ + row; if (gb > g.N - 1) gb = g.N - 1;
-            oa[i] = (uint32_t)((ga * g.lda + slot * 8) * 2);
-            ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
-        }
-    };
-    // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
-    auto dma = [&](int bufv, int kt, int p) {
-        if constexpr ((OTTER_DIAG & 1) != 0) return;
-        const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
-        if (p < 8)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)oa[p & 7],
-                                                     kt * 128, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[p & 7],
-                                                     kt * 128, 0, 0);
-    };
-    bool pre = false;   // K-tile 0 of the tile about to start is already in flight (PF)
-    int64_t pm0 = 0, pn0 = 0;
-    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-        int64_t m0, n0;
-        if (pre) {
-            m0 = pm0; n0 = pn0;
-        } else {
-            int tile_m, tile_n;
-            tile_of_block(g, vb, tile_m, tile_n);
-            m0 = (int64_t)tile_m * BM; n0 = (int64_t)tile_n * BN;
-        }
-        TMARK(0);
-        // ---- prologue: K-tiles 0 and 1 in flight, 0 readable; the 256 accumulator registers are zeroed while they land ----
-        if (!pre) {
-            set_offsets(m0, n0);
-#pragma unroll
-            for (int p = 0; p < 16; ++p) dma(0, 0, p);
-        }
-#pragma unroll
-        for (int p = 0; p < 16; ++p) dma(1, 1, p);
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16_t acc[4][4];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        bf16x8_t fm[4][4], fn[4][4];  // [k-step][32-row block]: fm = A rows (b-operand), fn = B rows (a-operand)
-        if constexpr ((OTTER_DIAG & 8) != 0) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    fm[ks][i] = fn[ks][i] = __builtin_bit_cast(bf16x8_t, uint4{0x3f803f80u + (unsigned)lane, 0x3f003f00u, 0x3e803e80u, 0x3f803f80u});
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            LDF(fn[0][i], rb, rb_hi, 0, 0, i);
-            LDF(fm[0][i], ra, ra_hi, 0, 0, i);
-        }
-        TMARK(1);
-#define MMA(KS, MI, NI)                                                                                                   \
-    do {                                                                                                                  \
-        if constexpr ((OTTER_DIAG & 2) == 0)                                                                              \
-            acc[MI][NI] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0);          \
-    } while (0)
-// ---- GENERATED by tools/gen/gemm_r4_schedule.py (do not edit by hand) ----
-#define KTILE_S0(BUF, TV, DMA, NEXT)                                                                                                                                                                                                   \
-    do {                                                                                                                                                                                                                               \
-        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                                                                 \
-        MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                                                                                                                                 \
-        MMA(0, 0, 1); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                                                                 \
-        MMA(0, 1, 1); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                                                                                                                                 \
-        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                                                                 \
-        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB();                                                                                                                                                                 \
-        MMA(0, 3, 0); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                                                                 \
-        MMA(0, 3, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                                                                                                                                 \
-        MMA(0, 0, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                                                                 \
-        MMA(0, 1, 2); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB();                                                                                                                                                                 \
-        MMA(0, 2, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                                                                 \
-        MMA(0, 3, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                                                                                                                                 \
-        MMA(0, 0, 3); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                                                                 \
-        MMA(0, 1, 3); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB();                                                                                                                                                                 \
-        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                                                                 \
-        MMA(0, 3, 3); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                                                                                                                                 \
-        MMA(1, 0, 0); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB();                                                                                                                                                                 \
-        MMA(1, 1, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                                                                                                                                 \
-        MMA(1, 0, 1); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB();                                                                                                                                                                 \
-        MMA(1, 1, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                                                                                                                                 \
-        MMA(1, 2, 0); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB();                                                                                                                                                                 \
-        MMA(1, 2, 1); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                                                                                                                                 \
-        MMA(1, 3, 0); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB();                                                                                                                                                                 \
-        MMA(1, 3, 1); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                                                                                                                                 \
-        MMA(1, 0, 2); SB();                                                                                                                                                                                                            \
-        MMA(1, 1, 2); SB();                                                                                                                                                                                                            \
-        MMA(1, 2, 2); SB();                                                                                                                                                                                                            \
-        MMA(1, 3, 2); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                                                                     \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                                                                      \
-        MMA(1, 1, 3); SB();                                                                                                                                                                                                            \
-        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                                                                      \
-        MMA(1, 3, 3); SB();                                                                                                                                                                                                            \
-        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                                                                      \
-        MMA(2, 1, 0); SB();                                                                                                                                                                                                            \
-        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                                                                      \
-        MMA(2, 1, 1); SB();                                                                                                                                                                                                            \
-        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                                                                      \
-        MMA(2, 2, 1); SB();                                                                                                                                                                                                            \
-        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                                                                      \
-        MMA(2, 3, 1); SB();                                                                                                                                                                                                            \
-        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                                                                      \
-        MMA(2, 1, 2); SB();                                                                                                                                                                                                            \
-        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                                                                      \
-        MMA(2, 3, 2); SB();                                                                                                                                                                                                            \
-        MMA(2, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                                                                      \
-        MMA(2, 1, 3); SB();                                                                                                                                                                                                            \
-        MMA(2, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                                                                      \
-        MMA(2, 3, 3); SB();                                                                                                                                                                                                            \
-        MMA(3, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
-        MMA(3, 1, 0); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                                                             \
-        MMA(3, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                                                                     \
-        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                                                             \
-        MMA(3, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                                                                     \
-        MMA(3, 2, 1); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                                                             \
-        MMA(3, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                                                                     \
-        MMA(3, 3, 1); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                                                             \
-        MMA(3, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                                                                     \
-        MMA(3, 1, 2); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                                                             \
-        MMA(3, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                                                                     \
-        MMA(3, 3, 2); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                                                             \
-        MMA(3, 0, 3); SB();                                                                                                                                                                                                            \
-        MMA(3, 1, 3); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                                                             \
-        MMA(3, 2, 3); SB();                                                                                                                                                                                                            \
-        MMA(3, 3, 3); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                                                             \
-    } while (0)
-#define KTILE_S1(BUF, TV, DMA, NEXT)                                                                                                                                                                                                   \
-    do {                                                                                                                                                                                                                               \
-        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                      \
-        MMA(0, 1, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                      \
-        MMA(0, 0, 1); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                      \
-        MMA(0, 1, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                      \
-        MMA(0, 2, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                                                                                      \
-        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                                                                                      \
-        MMA(0, 3, 0); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                                                                                      \
-        MMA(0, 3, 1); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                                                                                      \
-        MMA(0, 0, 2); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                                                                                      \
-        MMA(0, 1, 2); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                                                                                      \
-        MMA(0, 2, 2); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                                                                                      \
-        MMA(0, 3, 2); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                                                                                      \
-        MMA(0, 0, 3); SB();                                                                                                                                                                                                            \
-        MMA(0, 1, 3); SB();                                                                                                                                                                                                            \
-        MMA(0, 2, 3); SB();                                                                                                                                                                                                            \
-        MMA(0, 3, 3); SB();                                                                                                                                                                                                            \
-        MMA(1, 0, 0); SB();                                                                                                                                                                                                            \
-        MMA(1, 1, 0); SB();                                                                                                                                                                                                            \
-        MMA(1, 0, 1); SB();                                                                                                                                                                                                            \
-        MMA(1, 1, 1); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                                                                     \
-        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                                                                      \
-        MMA(1, 2, 1); SB();                                                                                                                                                                                                            \
-        MMA(1, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                                                                      \
-        MMA(1, 3, 1); SB();                                                                                                                                                                                                            \
-        MMA(1, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                                                                      \
-        MMA(1, 1, 2); SB();                                                                                                                                                                                                            \
-        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                                                                      \
-        MMA(1, 3, 2); SB();                                                                                                                                                                                                            \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                                                                      \
-        MMA(1, 1, 3); SB();                                                                                                                                                                                                            \
-        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                                                                      \
-        MMA(1, 3, 3); SB();                                                                                                                                                                                                            \
-        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                                                                      \
-        MMA(2, 1, 0); SB();                                                                                                                                                                                                            \
-        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                                                                      \
-        MMA(2, 1, 1); SB();                                                                                                                                                                                                            \
-        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                                                                      \
-        MMA(2, 2, 1); SB();                                                                                                                                                                                                            \
-        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                                                                      \
-        MMA(2, 3, 1); SB();                                                                                                                                                                                                            \
-        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                                                                     \
-        MMA(2, 1, 2); SB();                                                                                                                                                                                                            \
-        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
-        MMA(2, 3, 2); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                                                             \
-        MMA(2, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                                                                     \
-        MMA(2, 1, 3); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                                                             \
-        MMA(2, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                                                                     \
-        MMA(2, 3, 3); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                                                             \
-        MMA(3, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                                                                     \
-        MMA(3, 1, 0); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                                                             \
-        MMA(3, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                                                                     \
-        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                                                             \
-        MMA(3, 2, 0); SB();                                                                                                                                                                                                            \
-        MMA(3, 2, 1); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                                                             \
-        MMA(3, 3, 0); SB();                                                                                                                                                                                                            \
-        MMA(3, 3, 1); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                                                             \
-        MMA(3, 0, 2); SB();                                                                                                                                                                                                            \
-        MMA(3, 1, 2); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                                                             \
-        MMA(3, 2, 2); SB();                                                                                                                                                                                                            \
-        MMA(3, 3, 2); SB();                                                                                                                                                                                                            \
-        MMA(3, 0, 3); SB();                                                                                                                                                                                                            \
-        MMA(3, 1, 3); SB();                                                                                                                                                                                                            \
-        MMA(3, 2, 3); SB();                                                                                                                                                                                                            \
-        MMA(3, 3, 3); SB();                                                                                                                                                                                                            \
-    } while (0)
-#define KTILE_S2(BUF, TV, DMA, NEXT)                                                                                                                                                            \
-    do {                                                                                                                                                                                        \
-        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                                                                                          \
-        MMA(0, 0, 1); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 1, 1); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                                                                                          \
-        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB();                                                                                                                          \
-        MMA(0, 3, 0); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 3, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                                                                                          \
-        MMA(0, 0, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 1, 2); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB();                                                                                                                          \
-        MMA(0, 2, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 3, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                                                                                          \
-        MMA(0, 0, 3); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 1, 3); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB();                                                                                                                          \
-        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 3, 3); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                                                                                          \
-        MMA(1, 0, 0); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB();                                                                                                                          \
-        MMA(1, 1, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                                                                                          \
-        MMA(1, 0, 1); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB();                                                                                                                          \
-        MMA(1, 1, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                                                                                          \
-        MMA(1, 2, 0); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB();                                                                                                                          \
-        MMA(1, 2, 1); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                                                                                          \
-        MMA(1, 3, 0); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB();                                                                                                                          \
-        MMA(1, 3, 1); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                                                                                          \
-        MMA(1, 0, 2); SB();                                                                                                                                                                     \
-        MMA(1, 1, 2); SB();                                                                                                                                                                     \
-        MMA(1, 2, 2); SB();                                                                                                                                                                     \
-        MMA(1, 3, 2); SB();                                                                                                                                                                     \
-        MMA(1, 0, 3); SB();                                                                                                                                                                     \
-        MMA(1, 1, 3); SB();                                                                                                                                                                     \
-        MMA(1, 2, 3); SB();                                                                                                                                                                     \
-        MMA(1, 3, 3); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
-        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
-        MMA(2, 1, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
-        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
-        MMA(2, 1, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
-        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
-        MMA(2, 2, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
-        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
-        MMA(2, 3, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
-        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
-        MMA(2, 1, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
-        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
-        MMA(2, 3, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
-        MMA(2, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
-        MMA(2, 1, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
-        MMA(2, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
-        MMA(2, 3, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
-        MMA(3, 0, 0); SB();                                                                                                                                                                     \
-        MMA(3, 1, 0); SB();                                                                                                                                                                     \
-        MMA(3, 0, 1); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
-        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                       \
-        MMA(3, 2, 0); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                       \
-        MMA(3, 2, 1); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                       \
-        MMA(3, 3, 0); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                       \
-        MMA(3, 3, 1); SB();                                                                                                                                                                     \
-        MMA(3, 0, 2); SB();                                                                                                                                                                     \
-        MMA(3, 1, 2); SB();                                                                                                                                                                     \
-        MMA(3, 2, 2); SB();                                                                                                                                                                     \
-        MMA(3, 3, 2); SB();                                                                                                                                                                     \
-        MMA(3, 0, 3); SB();                                                                                                                                                                     \
-        MMA(3, 1, 3); SB();                                                                                                                                                                     \
-        MMA(3, 2, 3); SB();                                                                                                                                                                     \
-        MMA(3, 3, 3); SB();                                                                                                                                                                     \
-    } while (0)
-#define KTILE_S3(BUF, TV, DMA, NEXT)                                                                                         \
-    do {                                                                                                                     \
-        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                       \
-        MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                       \
-        MMA(0, 0, 1); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                       \
-        MMA(0, 1, 1); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                       \
-        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                       \
-        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB();                                                       \
-        MMA(0, 3, 0); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                       \
-        MMA(0, 3, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                       \
-        MMA(0, 0, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                       \
-        MMA(0, 1, 2); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB();                                                       \
-        MMA(0, 2, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                       \
-        MMA(0, 3, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                       \
-        MMA(0, 0, 3); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                       \
-        MMA(0, 1, 3); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB();                                                       \
-        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                       \
-        MMA(0, 3, 3); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                       \
-        MMA(1, 0, 0); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB();                                                       \
-        MMA(1, 1, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                       \
-        MMA(1, 0, 1); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB();                                                       \
-        MMA(1, 1, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                       \
-        MMA(1, 2, 0); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB();                                                       \
-        MMA(1, 2, 1); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                       \
-        MMA(1, 3, 0); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB();                                                       \
-        MMA(1, 3, 1); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                       \
-        MMA(1, 0, 2); SB();                                                                                                  \
-        MMA(1, 1, 2); SB();                                                                                                  \
-        MMA(1, 2, 2); SB();                                                                                                  \
-        MMA(1, 3, 2); SB(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();  \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                            \
-        MMA(1, 1, 3); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
-        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                            \
-        MMA(1, 3, 3); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
-        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                            \
-        MMA(2, 1, 0); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
-        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                            \
-        MMA(2, 1, 1); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
-        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                            \
-        MMA(2, 2, 1); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
-        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                            \
-        MMA(2, 3, 1); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
-        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                            \
-        MMA(2, 1, 2); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
-        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                            \
-        MMA(2, 3, 2); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
-        MMA(2, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                            \
-        MMA(2, 1, 3); SB();                                                                                                  \
-        MMA(2, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                            \
-        MMA(2, 3, 3); SB();                                                                                                  \
-        MMA(3, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                           \
-        MMA(3, 1, 0); SB();                                                                                                  \
-        MMA(3, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                           \
-        MMA(3, 1, 1); SB();                                                                                                  \
-        MMA(3, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                           \
-        MMA(3, 2, 1); SB();                                                                                                  \
-        MMA(3, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                           \
-        MMA(3, 3, 1); SB();                                                                                                  \
-        MMA(3, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                           \
-        MMA(3, 1, 2); SB();                                                                                                  \
-        MMA(3, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                           \
-        MMA(3, 3, 2); SB();                                                                                                  \
-        MMA(3, 0, 3); SB();                                                                                                  \
-        MMA(3, 1, 3); SB();                                                                                                  \
-        MMA(3, 2, 3); SB();                                                                                                  \
-        MMA(3, 3, 3); SB();                                                                                                  \
-    } while (0)
-#define KTILE_S4(BUF, TV, DMA, NEXT)                                                                                         \
-    do {                                                                                                                     \
-        MMA(0, 0, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                       \
-        MMA(0, 1, 0); SB(); LDF(fn[2][0], rb, rb_hi, BUF, 2, 0); SB();                                                       \
-        MMA(0, 0, 1); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                       \
-        MMA(0, 1, 1); SB(); LDF(fm[2][0], ra, ra_hi, BUF, 2, 0); SB();                                                       \
-        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                       \
-        MMA(0, 2, 1); SB(); LDF(fm[2][1], ra, ra_hi, BUF, 2, 1); SB();                                                       \
-        MMA(0, 3, 0); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                       \
-        MMA(0, 3, 1); SB(); LDF(fn[2][1], rb, rb_hi, BUF, 2, 1); SB();                                                       \
-        MMA(0, 0, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                       \
-        MMA(0, 1, 2); SB(); LDF(fm[2][2], ra, ra_hi, BUF, 2, 2); SB();                                                       \
-        MMA(0, 2, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                       \
-        MMA(0, 3, 2); SB(); LDF(fm[2][3], ra, ra_hi, BUF, 2, 3); SB();                                                       \
-        MMA(0, 0, 3); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                       \
-        MMA(0, 1, 3); SB(); LDF(fn[2][2], rb, rb_hi, BUF, 2, 2); SB();                                                       \
-        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                       \
-        MMA(0, 3, 3); SB(); LDF(fn[2][3], rb, rb_hi, BUF, 2, 3); SB();                                                       \
-        MMA(1, 0, 0); SB(); LDF(fn[3][0], rb, rb_hi, BUF, 3, 0); SB();                                                       \
-        MMA(1, 1, 0); SB(); LDF(fm[3][0], ra, ra_hi, BUF, 3, 0); SB();                                                       \
-        MMA(1, 0, 1); SB(); LDF(fm[3][1], ra, ra_hi, BUF, 3, 1); SB();                                                       \
-        MMA(1, 1, 1); SB(); LDF(fn[3][1], rb, rb_hi, BUF, 3, 1); SB();                                                       \
-        MMA(1, 2, 0); SB(); LDF(fm[3][2], ra, ra_hi, BUF, 3, 2); SB();                                                       \
-        MMA(1, 2, 1); SB(); LDF(fm[3][3], ra, ra_hi, BUF, 3, 3); SB();                                                       \
-        MMA(1, 3, 0); SB(); LDF(fn[3][2], rb, rb_hi, BUF, 3, 2); SB();                                                       \
-        MMA(1, 3, 1); SB(); LDF(fn[3][3], rb, rb_hi, BUF, 3, 3); SB();                                                       \
-        MMA(1, 0, 2); SB();                                                                                                  \
-        MMA(1, 1, 2); SB();                                                                                                  \
-        MMA(1, 2, 2); SB();                                                                                                  \
-        MMA(1, 3, 2); SB(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();  \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                            \
-        MMA(1, 1, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                            \
-        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                            \
-        MMA(1, 3, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                            \
-        MMA(2, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                            \
-        MMA(2, 1, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                            \
-        MMA(2, 0, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                            \
-        MMA(2, 1, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                            \
-        MMA(2, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                            \
-        MMA(2, 2, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                            \
-        MMA(2, 3, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                           \
-        MMA(2, 3, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                           \
-        MMA(2, 0, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                           \
-        MMA(2, 1, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                           \
-        MMA(2, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                           \
-        MMA(2, 3, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                           \
-        MMA(2, 0, 3); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
-        MMA(2, 1, 3); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
-        MMA(2, 2, 3); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
-        MMA(2, 3, 3); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
-        MMA(3, 0, 0); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
-        MMA(3, 1, 0); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
-        MMA(3, 0, 1); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
-        MMA(3, 1, 1); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
-        MMA(3, 2, 0); SB();                                                                                                  \
-        MMA(3, 2, 1); SB();                                                                                                  \
-        MMA(3, 3, 0); SB();                                                                                                  \
-        MMA(3, 3, 1); SB();                                                                                                  \
-        MMA(3, 0, 2); SB();                                                                                                  \
-        MMA(3, 1, 2); SB();                                                                                                  \
-        MMA(3, 2, 2); SB();                                                                                                  \
-        MMA(3, 3, 2); SB();                                                                                                  \
-        MMA(3, 0, 3); SB();                                                                                                  \
-        MMA(3, 1, 3); SB();                                                                                                  \
-        MMA(3, 2, 3); SB();                                                                                                  \
-        MMA(3, 3, 3); SB();                                                                                                  \
-    } while (0)
-// ---- end of generated schedule ----
-#define KLOOP(KT)                                   \
-    do {                                            \
-        int t = 0;                                  \
-        for (; t + 2 < nk; t += 2) {                \
-            KT(0, t, true, true);                   \
-            KT(1, t + 1, true, true);               \
-        }                                           \
-        KT(0, t, false, true);                      \
-        KT(1, t + 1, false, false);                 \
-    } while (0)
-        if constexpr (SCH == 0) KLOOP(KTILE_S0);
-        else if constexpr (SCH == 1) KLOOP(KTILE_S1);
-        else if constexpr (SCH == 2) KLOOP(KTILE_S2);
-        else if constexpr (SCH == 3) KLOOP(KTILE_S3);
-        else KLOOP(KTILE_S4);
-#undef KLOOP
-#undef KTILE_S0
-#undef KTILE_S1
-#undef KTILE_S2
-#undef KTILE_S3
-#undef KTILE_S4
-#undef MMA
-
-        // ---- epilogue: both buffers are dead (every fragment read retired before barrier #1 of the last K-tile, no DMA in flight) ----
-        TMARK(2);
-        float part = 0.f;
-        pre = false;
-        if constexpr (PF) {
-            const int nvb = vb + (int)gridDim.x;
-            if (nvb < ntiles) {
-                int tile_m, tile_n;
-                tile_of_block(g, nvb, tile_m, tile_n);
-                pm0 = (int64_t)tile_m * BM; pn0 = (int64_t)tile_n * BN;
-                set_offsets(pm0, pn0);
-#pragma unroll
-                for (int p = 0; p < 16; ++p) dma(0, 0, p);
-                pre = true;
-            }
-        }
-        char* park = smem + (PF ? TILE : 0);          // PF: the first buffer is filling
-        float* blk = reinterpret_cast<float*>(park) + wave * (32 * EPI_LD);
-        // full in-bounds tile with the wide bf16 / 16-byte f32 access shapes -> unrolled double-buffered tail, else the generic one
-        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (OTTER_DIAG & (4 | 16)) == 0 &&
-                          (g.cdt == OTTER_F32 || g.wide);
-        if (full) {
-            constexpr int NSP = PF ? 2 : TAIL_STRIPES;
-            float* blk2 = reinterpret_cast<float*>(park) + wave * (NSP * 32 * EPI_LD);
-            if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true, NSP>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
-            else part = tail_wave_full<EPI, false, NSP>(g, sgate, acc, blk2, m0 + wm * 128, n0 + wn * 128, lane);
-        } else {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            if constexpr ((OTTER_DIAG & 16) != 0) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) part += acc[mi][ni][r];
-                continue;
-            }
-#pragma unroll
-            for (int np = 0; np < 2; ++np) {
-                park_block(blk, acc[mi][2 * np], lane, 0);
-                park_block(blk, acc[mi][2 * np + 1], lane, 32);
-                __builtin_amdgcn_wave_barrier();
-                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 128 + mi * 32, n0 + wn * 128 + np * 64, lane);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        }
-        if constexpr ((OTTER_DIAG & 20) != 0) {
-            if (part == 12345.678f) reinterpret_cast<float*>(g.C)[threadIdx.x] = part;
-        }
-        TMARK(3);
-        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(park), vb);
-        __syncthreads();  // the next tile's prologue DMA overwrites the stripes
-        TMARK(4);
-        ++tcount;
-    }
-#undef LDF
-#undef SB
-#undef TMARK
-}
-
-#endif  // OTTER_EXPERIMENTAL (variants 4/5/12, 17, 18-23)
+#ifdef OTTER_EXPERIMENTAL  // tools-only: variants 4/5/12 (multi-stage ring), 17, 18-23 (one wave per SIMD, register-resident K-tile on 32x32x16): the round-1/2 generations that led to variant 26
+#include "experimental/gemm_generations_r1_r2.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // bf16 register-resident K-tile kernel on v_mfma_f32_16x16x32_bf16 (variant 26): variant 18's pipeline, LDS image and DMA
@@ -2960,402 +1857,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         MMA(1, 6, 7); SB(); if (NEXT) { LDFA(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
         MMA(1, 7, 7); SB(); if (NEXT) { LDFB(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
     } while (0)
-#ifdef OTTER_EXPERIMENTAL
-#define KTILE_T1(BUF, TV, DMA, NEXT)                                                                                                                                                            \
-    do {                                                                                                                                                                                        \
-        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 1, 0); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 0, 1); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 1, 1); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 2, 0); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 2, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 0, 2); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 1, 2); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 2, 2); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                          \
-        MMA(0, 3, 0); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                          \
-        MMA(0, 3, 1); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                          \
-        MMA(0, 3, 2); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                          \
-        MMA(0, 0, 3); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                          \
-        MMA(0, 1, 3); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                          \
-        MMA(0, 2, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                          \
-        MMA(0, 3, 3); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                          \
-        MMA(0, 4, 0); SB();                                                                                                                                                                     \
-        MMA(0, 4, 1); SB();                                                                                                                                                                     \
-        MMA(0, 4, 2); SB();                                                                                                                                                                     \
-        MMA(0, 4, 3); SB();                                                                                                                                                                     \
-        MMA(0, 0, 4); SB();                                                                                                                                                                     \
-        MMA(0, 1, 4); SB();                                                                                                                                                                     \
-        MMA(0, 2, 4); SB();                                                                                                                                                                     \
-        MMA(0, 3, 4); SB();                                                                                                                                                                     \
-        MMA(0, 4, 4); SB();                                                                                                                                                                     \
-        MMA(0, 5, 0); SB();                                                                                                                                                                     \
-        MMA(0, 5, 1); SB();                                                                                                                                                                     \
-        MMA(0, 5, 2); SB();                                                                                                                                                                     \
-        MMA(0, 5, 3); SB();                                                                                                                                                                     \
-        MMA(0, 5, 4); SB();                                                                                                                                                                     \
-        MMA(0, 0, 5); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
-        MMA(0, 1, 5); SB();                                                                                                                                                                     \
-        MMA(0, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
-        MMA(0, 3, 5); SB();                                                                                                                                                                     \
-        MMA(0, 4, 5); SB();                                                                                                                                                                     \
-        MMA(0, 5, 5); SB();                                                                                                                                                                     \
-        MMA(0, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
-        MMA(0, 6, 1); SB();                                                                                                                                                                     \
-        MMA(0, 6, 2); SB();                                                                                                                                                                     \
-        MMA(0, 6, 3); SB();                                                                                                                                                                     \
-        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
-        MMA(0, 6, 5); SB();                                                                                                                                                                     \
-        MMA(0, 0, 6); SB();                                                                                                                                                                     \
-        MMA(0, 1, 6); SB();                                                                                                                                                                     \
-        MMA(0, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
-        MMA(0, 3, 6); SB();                                                                                                                                                                     \
-        MMA(0, 4, 6); SB();                                                                                                                                                                     \
-        MMA(0, 5, 6); SB();                                                                                                                                                                     \
-        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
-        MMA(0, 7, 0); SB();                                                                                                                                                                     \
-        MMA(0, 7, 1); SB();                                                                                                                                                                     \
-        MMA(0, 7, 2); SB();                                                                                                                                                                     \
-        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
-        MMA(0, 7, 4); SB();                                                                                                                                                                     \
-        MMA(0, 7, 5); SB();                                                                                                                                                                     \
-        MMA(0, 7, 6); SB();                                                                                                                                                                     \
-        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
-        MMA(0, 1, 7); SB();                                                                                                                                                                     \
-        MMA(0, 2, 7); SB();                                                                                                                                                                     \
-        MMA(0, 3, 7); SB();                                                                                                                                                                     \
-        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
-        MMA(0, 5, 7); SB();                                                                                                                                                                     \
-        MMA(0, 6, 7); SB();                                                                                                                                                                     \
-        MMA(0, 7, 7); SB();                                                                                                                                                                     \
-        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
-        MMA(1, 1, 0); SB();                                                                                                                                                                     \
-        MMA(1, 0, 1); SB();                                                                                                                                                                     \
-        MMA(1, 1, 1); SB();                                                                                                                                                                     \
-        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
-        MMA(1, 2, 1); SB();                                                                                                                                                                     \
-        MMA(1, 0, 2); SB();                                                                                                                                                                     \
-        MMA(1, 1, 2); SB();                                                                                                                                                                     \
-        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
-        MMA(1, 3, 0); SB();                                                                                                                                                                     \
-        MMA(1, 3, 1); SB();                                                                                                                                                                     \
-        MMA(1, 3, 2); SB();                                                                                                                                                                     \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
-        MMA(1, 1, 3); SB();                                                                                                                                                                     \
-        MMA(1, 2, 3); SB();                                                                                                                                                                     \
-        MMA(1, 3, 3); SB();                                                                                                                                                                     \
-        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
-        MMA(1, 4, 1); SB();                                                                                                                                                                     \
-        MMA(1, 4, 2); SB();                                                                                                                                                                     \
-        MMA(1, 4, 3); SB();                                                                                                                                                                     \
-        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
-        MMA(1, 1, 4); SB();                                                                                                                                                                     \
-        MMA(1, 2, 4); SB();                                                                                                                                                                     \
-        MMA(1, 3, 4); SB();                                                                                                                                                                     \
-        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
-        MMA(1, 5, 0); SB();                                                                                                                                                                     \
-        MMA(1, 5, 1); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
-        MMA(1, 5, 2); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
-        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
-        MMA(1, 5, 4); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
-        MMA(1, 0, 5); SB();                                                                                                                                                                     \
-        MMA(1, 1, 5); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
-        MMA(1, 2, 5); SB();                                                                                                                                                                     \
-        MMA(1, 3, 5); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
-        MMA(1, 4, 5); SB();                                                                                                                                                                     \
-        MMA(1, 5, 5); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
-        MMA(1, 6, 0); SB();                                                                                                                                                                     \
-        MMA(1, 6, 1); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
-        MMA(1, 6, 2); SB();                                                                                                                                                                     \
-        MMA(1, 6, 3); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
-        MMA(1, 6, 4); SB();                                                                                                                                                                     \
-        MMA(1, 6, 5); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
-        MMA(1, 0, 6); SB();                                                                                                                                                                     \
-        MMA(1, 1, 6); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
-        MMA(1, 2, 6); SB();                                                                                                                                                                     \
-        MMA(1, 3, 6); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
-        MMA(1, 4, 6); SB();                                                                                                                                                                     \
-        MMA(1, 5, 6); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
-        MMA(1, 6, 6); SB();                                                                                                                                                                     \
-        MMA(1, 7, 0); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
-        MMA(1, 7, 1); SB();                                                                                                                                                                     \
-        MMA(1, 7, 2); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
-        MMA(1, 7, 3); SB();                                                                                                                                                                     \
-        MMA(1, 7, 4); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
-        MMA(1, 7, 5); SB();                                                                                                                                                                     \
-        MMA(1, 7, 6); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
-        MMA(1, 0, 7); SB();                                                                                                                                                                     \
-        MMA(1, 1, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
-        MMA(1, 2, 7); SB();                                                                                                                                                                     \
-        MMA(1, 3, 7); SB();                                                                                                                                                                     \
-        MMA(1, 4, 7); SB();                                                                                                                                                                     \
-        MMA(1, 5, 7); SB();                                                                                                                                                                     \
-        MMA(1, 6, 7); SB();                                                                                                                                                                     \
-        MMA(1, 7, 7); SB();                                                                                                                                                                     \
-    } while (0)
-#define KTILE_T2(BUF, TV, DMA, NEXT)                                                                                                                                                            \
-    do {                                                                                                                                                                                        \
-        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 1, 0); SB();                                                                                                                                                                     \
-        MMA(0, 0, 1); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 1, 1); SB();                                                                                                                                                                     \
-        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 2, 1); SB();                                                                                                                                                                     \
-        MMA(0, 0, 2); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 1, 2); SB();                                                                                                                                                                     \
-        MMA(0, 2, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 3, 0); SB();                                                                                                                                                                     \
-        MMA(0, 3, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 3, 2); SB();                                                                                                                                                                     \
-        MMA(0, 0, 3); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 1, 3); SB();                                                                                                                                                                     \
-        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 3, 3); SB();                                                                                                                                                                     \
-        MMA(0, 4, 0); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                          \
-        MMA(0, 4, 1); SB();                                                                                                                                                                     \
-        MMA(0, 4, 2); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                          \
-        MMA(0, 4, 3); SB();                                                                                                                                                                     \
-        MMA(0, 0, 4); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                          \
-        MMA(0, 1, 4); SB();                                                                                                                                                                     \
-        MMA(0, 2, 4); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                          \
-        MMA(0, 3, 4); SB();                                                                                                                                                                     \
-        MMA(0, 4, 4); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                          \
-        MMA(0, 5, 0); SB();                                                                                                                                                                     \
-        MMA(0, 5, 1); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                          \
-        MMA(0, 5, 2); SB();                                                                                                                                                                     \
-        MMA(0, 5, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                          \
-        MMA(0, 5, 4); SB();                                                                                                                                                                     \
-        MMA(0, 0, 5); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                          \
-        MMA(0, 1, 5); SB();                                                                                                                                                                     \
-        MMA(0, 2, 5); SB();                                                                                                                                                                     \
-        MMA(0, 3, 5); SB();                                                                                                                                                                     \
-        MMA(0, 4, 5); SB();                                                                                                                                                                     \
-        MMA(0, 5, 5); SB();                                                                                                                                                                     \
-        MMA(0, 6, 0); SB();                                                                                                                                                                     \
-        MMA(0, 6, 1); SB();                                                                                                                                                                     \
-        MMA(0, 6, 2); SB();                                                                                                                                                                     \
-        MMA(0, 6, 3); SB();                                                                                                                                                                     \
-        MMA(0, 6, 4); SB();                                                                                                                                                                     \
-        MMA(0, 6, 5); SB();                                                                                                                                                                     \
-        MMA(0, 0, 6); SB();                                                                                                                                                                     \
-        MMA(0, 1, 6); SB();                                                                                                                                                                     \
-        MMA(0, 2, 6); SB();                                                                                                                                                                     \
-        MMA(0, 3, 6); SB();                                                                                                                                                                     \
-        MMA(0, 4, 6); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
-        MMA(0, 5, 6); SB();                                                                                                                                                                     \
-        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
-        MMA(0, 7, 0); SB();                                                                                                                                                                     \
-        MMA(0, 7, 1); SB();                                                                                                                                                                     \
-        MMA(0, 7, 2); SB();                                                                                                                                                                     \
-        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
-        MMA(0, 7, 4); SB();                                                                                                                                                                     \
-        MMA(0, 7, 5); SB();                                                                                                                                                                     \
-        MMA(0, 7, 6); SB();                                                                                                                                                                     \
-        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
-        MMA(0, 1, 7); SB();                                                                                                                                                                     \
-        MMA(0, 2, 7); SB();                                                                                                                                                                     \
-        MMA(0, 3, 7); SB();                                                                                                                                                                     \
-        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
-        MMA(0, 5, 7); SB();                                                                                                                                                                     \
-        MMA(0, 6, 7); SB();                                                                                                                                                                     \
-        MMA(0, 7, 7); SB();                                                                                                                                                                     \
-        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
-        MMA(1, 1, 0); SB();                                                                                                                                                                     \
-        MMA(1, 0, 1); SB();                                                                                                                                                                     \
-        MMA(1, 1, 1); SB();                                                                                                                                                                     \
-        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
-        MMA(1, 2, 1); SB();                                                                                                                                                                     \
-        MMA(1, 0, 2); SB();                                                                                                                                                                     \
-        MMA(1, 1, 2); SB();                                                                                                                                                                     \
-        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
-        MMA(1, 3, 0); SB();                                                                                                                                                                     \
-        MMA(1, 3, 1); SB();                                                                                                                                                                     \
-        MMA(1, 3, 2); SB();                                                                                                                                                                     \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
-        MMA(1, 1, 3); SB();                                                                                                                                                                     \
-        MMA(1, 2, 3); SB();                                                                                                                                                                     \
-        MMA(1, 3, 3); SB();                                                                                                                                                                     \
-        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
-        MMA(1, 4, 1); SB();                                                                                                                                                                     \
-        MMA(1, 4, 2); SB();                                                                                                                                                                     \
-        MMA(1, 4, 3); SB();                                                                                                                                                                     \
-        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
-        MMA(1, 1, 4); SB();                                                                                                                                                                     \
-        MMA(1, 2, 4); SB();                                                                                                                                                                     \
-        MMA(1, 3, 4); SB();                                                                                                                                                                     \
-        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
-        MMA(1, 5, 0); SB();                                                                                                                                                                     \
-        MMA(1, 5, 1); SB();                                                                                                                                                                     \
-        MMA(1, 5, 2); SB();                                                                                                                                                                     \
-        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
-        MMA(1, 5, 4); SB();                                                                                                                                                                     \
-        MMA(1, 0, 5); SB();                                                                                                                                                                     \
-        MMA(1, 1, 5); SB();                                                                                                                                                                     \
-        MMA(1, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
-        MMA(1, 3, 5); SB();                                                                                                                                                                     \
-        MMA(1, 4, 5); SB();                                                                                                                                                                     \
-        MMA(1, 5, 5); SB();                                                                                                                                                                     \
-        MMA(1, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
-        MMA(1, 6, 1); SB();                                                                                                                                                                     \
-        MMA(1, 6, 2); SB();                                                                                                                                                                     \
-        MMA(1, 6, 3); SB();                                                                                                                                                                     \
-        MMA(1, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
-        MMA(1, 6, 5); SB();                                                                                                                                                                     \
-        MMA(1, 0, 6); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
-        MMA(1, 1, 6); SB();                                                                                                                                                                     \
-        MMA(1, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                               \
-        MMA(1, 3, 6); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
-        MMA(1, 4, 6); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
-        MMA(1, 5, 6); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
-        MMA(1, 6, 6); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
-        MMA(1, 7, 0); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
-        MMA(1, 7, 1); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
-        MMA(1, 7, 2); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
-        MMA(1, 7, 3); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
-        MMA(1, 7, 4); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
-        MMA(1, 7, 5); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
-        MMA(1, 7, 6); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
-        MMA(1, 0, 7); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
-        MMA(1, 1, 7); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
-        MMA(1, 2, 7); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
-        MMA(1, 3, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
-        MMA(1, 4, 7); SB();                                                                                                                                                                     \
-        MMA(1, 5, 7); SB();                                                                                                                                                                     \
-        MMA(1, 6, 7); SB();                                                                                                                                                                     \
-        MMA(1, 7, 7); SB();                                                                                                                                                                     \
-    } while (0)
-#define KTILE_T3(BUF, TV, DMA, NEXT)                                                                                         \
-    do {                                                                                                                     \
-        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                       \
-        MMA(0, 1, 0); SB();                                                                                                  \
-        MMA(0, 0, 1); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                       \
-        MMA(0, 1, 1); SB();                                                                                                  \
-        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                       \
-        MMA(0, 2, 1); SB();                                                                                                  \
-        MMA(0, 0, 2); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                       \
-        MMA(0, 1, 2); SB();                                                                                                  \
-        MMA(0, 2, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                       \
-        MMA(0, 3, 0); SB();                                                                                                  \
-        MMA(0, 3, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                       \
-        MMA(0, 3, 2); SB();                                                                                                  \
-        MMA(0, 0, 3); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                       \
-        MMA(0, 1, 3); SB();                                                                                                  \
-        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                       \
-        MMA(0, 3, 3); SB();                                                                                                  \
-        MMA(0, 4, 0); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                       \
-        MMA(0, 4, 1); SB();                                                                                                  \
-        MMA(0, 4, 2); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                       \
-        MMA(0, 4, 3); SB();                                                                                                  \
-        MMA(0, 0, 4); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                       \
-        MMA(0, 1, 4); SB();                                                                                                  \
-        MMA(0, 2, 4); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                       \
-        MMA(0, 3, 4); SB();                                                                                                  \
-        MMA(0, 4, 4); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                       \
-        MMA(0, 5, 0); SB();                                                                                                  \
-        MMA(0, 5, 1); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                       \
-        MMA(0, 5, 2); SB();                                                                                                  \
-        MMA(0, 5, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                       \
-        MMA(0, 5, 4); SB();                                                                                                  \
-        MMA(0, 0, 5); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                       \
-        MMA(0, 1, 5); SB();                                                                                                  \
-        MMA(0, 2, 5); SB();                                                                                                  \
-        MMA(0, 3, 5); SB();                                                                                                  \
-        MMA(0, 4, 5); SB();                                                                                                  \
-        MMA(0, 5, 5); SB();                                                                                                  \
-        MMA(0, 6, 0); SB();                                                                                                  \
-        MMA(0, 6, 1); SB();                                                                                                  \
-        MMA(0, 6, 2); SB(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();  \
-        MMA(0, 6, 3); SB();                                                                                                  \
-        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                            \
-        MMA(0, 6, 5); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
-        MMA(0, 0, 6); SB();                                                                                                  \
-        MMA(0, 1, 6); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                   \
-        MMA(0, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                            \
-        MMA(0, 3, 6); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
-        MMA(0, 4, 6); SB();                                                                                                  \
-        MMA(0, 5, 6); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                   \
-        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                            \
-        MMA(0, 7, 0); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
-        MMA(0, 7, 1); SB();                                                                                                  \
-        MMA(0, 7, 2); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                   \
-        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                            \
-        MMA(0, 7, 4); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
-        MMA(0, 7, 5); SB();                                                                                                  \
-        MMA(0, 7, 6); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                   \
-        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                            \
-        MMA(0, 1, 7); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                   \
-        MMA(0, 2, 7); SB();                                                                                                  \
-        MMA(0, 3, 7); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                   \
-        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                            \
-        MMA(0, 5, 7); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                   \
-        MMA(0, 6, 7); SB();                                                                                                  \
-        MMA(0, 7, 7); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                   \
-        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                            \
-        MMA(1, 1, 0); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                   \
-        MMA(1, 0, 1); SB();                                                                                                  \
-        MMA(1, 1, 1); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                   \
-        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                            \
-        MMA(1, 2, 1); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                   \
-        MMA(1, 0, 2); SB();                                                                                                  \
-        MMA(1, 1, 2); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                   \
-        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                            \
-        MMA(1, 3, 0); SB();                                                                                                  \
-        MMA(1, 3, 1); SB();                                                                                                  \
-        MMA(1, 3, 2); SB();                                                                                                  \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                            \
-        MMA(1, 1, 3); SB();                                                                                                  \
-        MMA(1, 2, 3); SB();                                                                                                  \
-        MMA(1, 3, 3); SB();                                                                                                  \
-        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                           \
-        MMA(1, 4, 1); SB();                                                                                                  \
-        MMA(1, 4, 2); SB();                                                                                                  \
-        MMA(1, 4, 3); SB();                                                                                                  \
-        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                           \
-        MMA(1, 1, 4); SB();                                                                                                  \
-        MMA(1, 2, 4); SB();                                                                                                  \
-        MMA(1, 3, 4); SB();                                                                                                  \
-        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                           \
-        MMA(1, 5, 0); SB();                                                                                                  \
-        MMA(1, 5, 1); SB();                                                                                                  \
-        MMA(1, 5, 2); SB();                                                                                                  \
-        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                           \
-        MMA(1, 5, 4); SB();                                                                                                  \
-        MMA(1, 0, 5); SB();                                                                                                  \
-        MMA(1, 1, 5); SB();                                                                                                  \
-        MMA(1, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                           \
-        MMA(1, 3, 5); SB();                                                                                                  \
-        MMA(1, 4, 5); SB();                                                                                                  \
-        MMA(1, 5, 5); SB();                                                                                                  \
-        MMA(1, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                           \
-        MMA(1, 6, 1); SB();                                                                                                  \
-        MMA(1, 6, 2); SB();                                                                                                  \
-        MMA(1, 6, 3); SB();                                                                                                  \
-        MMA(1, 6, 4); SB();                                                                                                  \
-        MMA(1, 6, 5); SB();                                                                                                  \
-        MMA(1, 0, 6); SB();                                                                                                  \
-        MMA(1, 1, 6); SB();                                                                                                  \
-        MMA(1, 2, 6); SB();                                                                                                  \
-        MMA(1, 3, 6); SB();                                                                                                  \
-        MMA(1, 4, 6); SB();                                                                                                  \
-        MMA(1, 5, 6); SB();                                                                                                  \
-        MMA(1, 6, 6); SB();                                                                                                  \
-        MMA(1, 7, 0); SB();                                                                                                  \
-        MMA(1, 7, 1); SB();                                                                                                  \
-        MMA(1, 7, 2); SB();                                                                                                  \
-        MMA(1, 7, 3); SB();                                                                                                  \
-        MMA(1, 7, 4); SB();                                                                                                  \
-        MMA(1, 7, 5); SB();                                                                                                  \
-        MMA(1, 7, 6); SB();                                                                                                  \
-        MMA(1, 0, 7); SB();                                                                                                  \
-        MMA(1, 1, 7); SB();                                                                                                  \
-        MMA(1, 2, 7); SB();                                                                                                  \
-        MMA(1, 3, 7); SB();                                                                                                  \
-        MMA(1, 4, 7); SB();                                                                                                  \
-        MMA(1, 5, 7); SB();                                                                                                  \
-        MMA(1, 6, 7); SB();                                                                                                  \
-        MMA(1, 7, 7); SB();                                                                                                  \
-    } while (0)
-// ---- end of generated schedule ----
-#endif  // OTTER_EXPERIMENTAL (alternative placements T1-T3)
+#ifdef OTTER_EXPERIMENTAL  // tools-only: variants 27-29: alternative slot placements T1-T3 of variant 26's K-tile schedule (generated by tools/gen/gemm_t4_schedule.py)
+#include "experimental/gemm_t4_placements_t1_t3.inc"
+#endif
 #define KLOOP(KT)                                   \
     do {                                            \
         int t = 0;                                  \

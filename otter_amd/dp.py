@@ -43,13 +43,19 @@ class GradReducer:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 640 << 20,
                  process_group: Optional[dist.ProcessGroup] = None, grad_dtype: torch.dtype = torch.float32, force: bool = False,
-                 row_only: Optional[dict] = None):
+                 row_only: Optional[dict] = None, overlap: Optional[bool] = None):
         """row_only: {parameter: row} -- parameters whose gradient is known to be zero outside ONE row when wait() is called
         (the reference's `--mask_lm_head`, train.mask_embedding): they stay out of the buckets, keep an ordinary .grad, and only
         that row is averaged across ranks."""
         self.group = process_group
         self.row_only = dict(row_only or {})
         self.force = force  # run the collectives even with one rank (exercises the RCCL path on a single GPU)
+        # overlap=False (or OTTER_DP_OVERLAP=0): no collective is launched from the gradient hooks; every bucket is reduced in wait(),
+        # after backward -- the A/B leg for a multi-GPU run (is the resident RCCL kernel costing the backward GEMMs more than the
+        # overlap hides?  DESIGN.md section 7).  Same collectives, same order, same results.
+        import os as _os
+
+        self.overlap = (_os.environ.get("OTTER_DP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         ps = [p for p in params if p.requires_grad and p not in self.row_only]
         if not ps:
@@ -134,7 +140,7 @@ class GradReducer:
         # backward launch each bucket as its last gradient arrives (the overlap) instead of everything serialising in wait()
         b = self._owner[p]
         b.ready.add(id(p))
-        if len(b.ready) == len(b.params) and b.work is None and self.sync and (self.world > 1 or self.force):
+        if len(b.ready) == len(b.params) and b.work is None and self.sync and self.overlap and (self.world > 1 or self.force):
             self._launch(b)
 
     def _launch(self, b: _Bucket):

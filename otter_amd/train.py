@@ -252,7 +252,7 @@ class TrainStep:
     def __init__(self, model, lr: float = 1e-5, weight_decay: float = 0.1, max_grad_norm: float = 1.0,
                  autocast_dtype: Optional[torch.dtype] = torch.bfloat16, process_group=None, bucket_bytes: int = 640 << 20,
                  fused_optimizer: bool = True, force_reducer: bool = False, hip_optimizer: Optional[bool] = None,
-                 mask_lm_head: bool = False, answer_token_id: Optional[int] = None):
+                 mask_lm_head: bool = False, answer_token_id: Optional[int] = None, dp_overlap: Optional[bool] = None):
         """mask_lm_head + answer_token_id: the reference's `--mask_lm_head` (instruction_following.py:228-244): only the <answer>
         row of the input (MPT: tied) embedding gradient -- and of lm_head for a LLaMA host -- survives.  Masking commutes with the
         DP average, so with a reducer those tensors leave the flat buckets and ONE ROW each is all-reduced (16 KB instead of
@@ -287,7 +287,8 @@ class TrainStep:
             self.embed_sink = SparseEmbedSink()    # installed as functional.embed_sink only for the duration of a step (see __call__)
         row_only = {m.weight: self.answer_token_id for m in self.masked_embeddings if m.weight.requires_grad}
         # single rank: gradients stay ordinary .grad tensors (no bucket indirection, nothing to reduce)
-        self.reducer = (GradReducer(self.params, bucket_bytes, process_group, force=force_reducer, row_only=row_only)
+        # dp_overlap=False: the buckets are reduced after backward instead of from the gradient hooks (A/B switch, GradReducer.overlap)
+        self.reducer = (GradReducer(self.params, bucket_bytes, process_group, force=force_reducer, row_only=row_only, overlap=dp_overlap)
                         if (self.world > 1 or force_reducer) else None)
         # With a reducer live RCCL's kernels hold CUs during the backward GEMMs.  A persistent grid (one workgroup per CU walking 4 tiles)
         # assumes it owns the chip: the workgroups that cannot start run their tile lists after the others have finished and the launch

@@ -79,6 +79,16 @@ def _worker(rank, world, port, q):
                 assert p.grad.data_ptr() == red2._view[p].data_ptr()
         red2.close()
         assert OF.grad_sink is None
+        # overlap=False (bench.py --dp-overlap off): nothing is launched from the hooks, every bucket is reduced in wait(); same gradients
+        red3 = GradReducer(net.parameters(), bucket_bytes=2048, overlap=False)
+        red3.zero_grad()
+        ((net(X[rank::world]) - Y[rank::world]) ** 2).mean().backward()
+        assert all(b.work is None for b in red3.buckets), "overlap=False must not launch from the gradient hooks"
+        red3.wait()
+        for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+            if p.requires_grad:
+                assert torch.allclose(p.grad, pr.grad, atol=1e-6), n
+        red3.close()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

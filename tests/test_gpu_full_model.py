@@ -239,7 +239,16 @@ def _grad_report(model, ref_g, tag):
         rec[n] = [l2, mx, cs]
         if l2 > worst:
             worst, worst_name = l2, n
-    # the tied embedding separately on the rows the batch looks up (lookup gradient + un-embedding gradient meet there)
+    # The 16 scalar gate gradients (attn_gate / ff_gate: ONE number = a signed sum over every element of a [tokens, 4096] branch output)
+    # are judged against the scale of the gate gradients as a group: a gate whose true gradient happens to be near zero has no meaningful
+    # relative error of its own in bf16 (round 5: blocks.23 attn_gate 19 % of ITS value = 0.4 % of the largest gate gradient).  The fp32
+    # mode is unaffected (every gate within 1e-5 either way).
+    gates = [n for n in names if ref_g[n].size == 1]
+    scale = max(abs(float(ref_g[n].reshape(-1)[0])) for n in gates)
+    for n in gates:
+        d = abs(float(prm[n].grad.reshape(-1)[0]) - float(ref_g[n].reshape(-1)[0]))
+        rec[n] = [d / scale, d / scale, 1.0]
+    worst, worst_name = max((v[0], k) for k, v in rec.items())
     return rec, worst, worst_name
 
 
