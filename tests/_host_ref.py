@@ -1,0 +1,127 @@
+"""TEST INFRASTRUCTURE -- host-side (CPU, fp32) reference of an OTTER model over a LLaMA decoder, composed exactly as the reference
+composes it (modeling_otter.py:420-442 OtterLayer: gated cross-attention block, THEN the wrapped decoder layer; :486-510 media locations from
+the <image> token; :975-997 vision encode): the third-party class the reference instantiates for the host (transformers' LlamaForCausalLM,
+modeling_otter.py:54,759-767) with the numpy oracle's gated cross-attention blocks hooked in front of the decoder layers that carry one, fed by the
+oracle's CLIP + perceiver.  Pinned on the CPU against the reference-generated fixture tests/golden/otter_tiny_llama.npz
+(tests/test_llama_host.py::test_host_reference_composition_reproduces_the_reference_fixture); used at full size by
+tests/test_gpu_full_model_c4_c5.py.  Imported by tests only."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import otter_oracle as O
+
+
+def new_hf_llama(text_cfg: dict):
+    """transformers.LlamaForCausalLM(fp32, CPU) WITHOUT the random initialisation pass (6.7 B normal_() draws on the host take minutes):
+    storage is allocated, every parameter is then overwritten by load_decoder_weights."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(**{k: v for k, v in text_cfg.items() if k not in ("architectures", "model_type", "_name_or_path")})
+    try:
+        from transformers.initialization import no_init_weights
+    except Exception:                                                    # older transformers
+        from transformers.modeling_utils import no_init_weights
+    with no_init_weights():
+        m = LlamaForCausalLM(cfg)
+    return m.float().eval()
+
+
+def load_decoder_weights(hf, otter_lang_encoder_state: dict):
+    """Copy the LLaMA host's weights out of an otter_amd (or reference) `lang_encoder` state dict: keys `model.layers.i.decoder_layer.*`
+    -> `model.layers.i.*`; the gated blocks' keys are skipped (they go to the oracle)."""
+    own = dict(hf.named_parameters())
+    seen = set()
+    with torch.no_grad():
+        for k, v in otter_lang_encoder_state.items():
+            if ".gated_cross_attn_layer." in k:
+                continue
+            hk = k.replace(".decoder_layer.", ".")
+            if hk in own:
+                own[hk].copy_(v.detach().to("cpu", torch.float32))
+                seen.add(hk)
+    missing = sorted(set(own) - seen)
+    assert not missing, missing[:5]
+
+
+def otter_llama_forward(hf, p: dict, spec: O.OtterSpec, vision_x: np.ndarray, ids: np.ndarray, labels=None, layer_prefix="lang_encoder.model.layers."):
+    """logits [B, T, V] (and loss) of the composed model.  p: numpy state dict holding vision_encoder.*, perceiver.* and the gated blocks."""
+    vis, _ = O.otter_encode_vision(p, spec, vision_x)
+    ml = np.asarray(ids) == spec.media_token_id
+    hooks = []
+
+    def make(i):
+        pre = layer_prefix + "%d.gated_cross_attn_layer." % i
+
+        def hook(mod, args, kwargs):
+            h = args[0] if args else kwargs["hidden_states"]
+            y, _ = O.gated_xattn_block_fwd(p, pre, h.detach().numpy().astype(np.float32), vis, ml, True, spec.immediate, spec.xattn_heads)
+            t = torch.from_numpy(np.ascontiguousarray(y)).to(h.dtype)
+            if args:
+                return (t,) + tuple(args[1:]), kwargs
+            kwargs = dict(kwargs)
+            kwargs["hidden_states"] = t
+            return args, kwargs
+
+        return hook
+
+    for i, layer in enumerate(hf.model.layers):
+        if spec.has_xattn(i):
+            hooks.append(layer.register_forward_pre_hook(make(i), with_kwargs=True))
+    try:
+        with torch.no_grad():
+            out = hf(input_ids=torch.from_numpy(np.asarray(ids)), labels=None if labels is None else torch.from_numpy(np.asarray(labels)))
+    finally:
+        for h in hooks:
+            h.remove()
+    return dict(logits=out.logits.float().numpy(), loss=None if labels is None else float(out.loss), vis=vis)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# OtterHD / Fuyu (config C5)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def new_hf_persimmon(text_cfg: dict):
+    """transformers.PersimmonForCausalLM (fp32, CPU) without the random-initialisation pass -- the class the reference's in-repo
+    fuyu/modeling_persimmon.py restates (and falls back to without flash-attn)."""
+    from transformers import PersimmonConfig, PersimmonForCausalLM
+
+    cfg = PersimmonConfig(**{k: v for k, v in text_cfg.items() if k not in ("model_type",)})
+    try:
+        from transformers.initialization import no_init_weights
+    except Exception:
+        from transformers.modeling_utils import no_init_weights
+    with no_init_weights():
+        m = PersimmonForCausalLM(cfg)
+    return m.float().eval()
+
+
+def fuyu_forward(hf_lm, fuyu_state: dict, ids, patches, patch_indices, labels=None, attention_mask=None):
+    """The reference's FuyuForCausalLM.forward (fuyu/modeling_fuyu.py:88-177) restated around transformers' Persimmon decoder:
+    word embeddings, `vision_embed_tokens` = Linear(patch_dim -> hidden) on the patches (:126), gather_continuous_embeddings (:44-77: position
+    j of sample b with patch_indices[b, j] = k >= 0 takes patch embedding k), the decoder on inputs_embeds, CE on labels shifted by one.
+    (transformers 5.x's own FuyuForCausalLM no longer takes image_patches_indices -- it keys on an image placeholder token -- so the wrapper
+    the reference has in-repo is what is restated here; pinned on tests/golden/fuyu_tiny.npz by tests/test_fuyu_host.py.)
+    fuyu_state: otter_amd / reference state dict (keys language_model.*, vision_embed_tokens.*), torch tensors."""
+    own = dict(hf_lm.named_parameters())
+    with torch.no_grad():
+        for k, v in fuyu_state.items():
+            if k.startswith("language_model.") and k[len("language_model."):] in own:
+                own[k[len("language_model."):]].copy_(v.detach().to("cpu", torch.float32))
+        W = fuyu_state["vision_embed_tokens.weight"].detach().to("cpu", torch.float32)
+        b = fuyu_state["vision_embed_tokens.bias"].detach().to("cpu", torch.float32)
+        ids_t = torch.as_tensor(np.asarray(ids))
+        emb = hf_lm.model.embed_tokens(ids_t).clone()
+        pe = torch.as_tensor(np.asarray(patches), dtype=torch.float32) @ W.t() + b          # [B, n_patches, hidden]
+        idx = torch.as_tensor(np.asarray(patch_indices))
+        for bi in range(emb.shape[0]):
+            dst = torch.nonzero(idx[bi] >= 0, as_tuple=True)[0]
+            src = idx[bi][dst]
+            if src.numel() > pe.shape[1]:
+                raise ValueError("Number of continuous embeddings does not match the number of continuous token ids")
+            emb[bi, dst] = pe[bi, src]
+        am = None if attention_mask is None else torch.as_tensor(np.asarray(attention_mask))
+        out = hf_lm(inputs_embeds=emb, attention_mask=am, labels=None if labels is None else torch.as_tensor(np.asarray(labels)))
+    return dict(logits=out.logits.float().numpy(), loss=None if labels is None else float(out.loss))

@@ -127,3 +127,23 @@ def test_persimmon_use_cache_follows_config():
     assert model(input_ids=t(ids), image_patches=t(patches), image_patches_indices=t(idx), use_cache=False).past_key_values is None
     txt = model.language_model.generate(t(ids[:, :6]), max_new_tokens=3, eos_token_id=-1)
     assert txt.shape == (ids.shape[0], 9)
+
+
+def test_host_reference_composition_reproduces_the_reference_fixture():
+    """tests/_host_ref.fuyu_forward (transformers' PersimmonForCausalLM + the restated patch-embedding scatter: the host-side reference of the
+    full-depth C5 parity test, tests/test_gpu_full_model_c4_c5.py) against the fixture produced by the REFERENCE's own FuyuForCausalLM."""
+    from tests import _host_ref as H
+
+    cfg = tiny_fuyu_config()
+    m = G.meta()["fuyu_tiny"]
+    sd = synth.state_dict_for(SEED, {k: tuple(s) for k, s in m["shapes"].items()})
+    gold = G.load("fuyu_tiny")
+    ids, patches, idx, mask, labels = tiny_fuyu_batch()
+    tc = cfg.text_config.to_dict() if hasattr(cfg.text_config, "to_dict") else dict(cfg.text_config)
+    keep = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "max_position_embeddings", "qk_layernorm",
+            "partial_rotary_factor", "hidden_act", "layer_norm_eps", "rope_theta", "tie_word_embeddings", "rope_parameters")
+    hf = H.new_hf_persimmon({k: tc[k] for k in keep if k in tc})
+    out = H.fuyu_forward(hf, {k: torch.from_numpy(v) for k, v in sd.items()}, ids, patches, idx, labels, attention_mask=mask)
+    valid = mask.astype(bool)
+    assert G.rel_err(out["logits"][valid], gold["logits"][valid]) < 2e-4
+    assert abs(out["loss"] - float(gold["loss"])) < 2e-4 * abs(float(gold["loss"]))
