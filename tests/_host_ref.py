@@ -45,8 +45,12 @@ def load_decoder_weights(hf, otter_lang_encoder_state: dict):
     assert not missing, missing[:5]
 
 
-def otter_llama_forward(hf, p: dict, spec: O.OtterSpec, vision_x: np.ndarray, ids: np.ndarray, labels=None, layer_prefix="lang_encoder.model.layers."):
-    """logits [B, T, V] (and loss) of the composed model.  p: numpy state dict holding vision_encoder.*, perceiver.* and the gated blocks."""
+def otter_llama_forward(hf, p: dict, spec: O.OtterSpec, vision_x: np.ndarray, ids: np.ndarray, labels=None, layer_prefix="lang_encoder.model.layers.",
+                        autocast_bf16: bool = False):
+    """logits [B, T, V] (and loss) of the composed model.  p: numpy state dict holding vision_encoder.*, perceiver.* and the gated blocks.
+    autocast_bf16: the decoder runs under torch.autocast("cpu", bfloat16) -- the precision mode the reference trains in
+    (instruction_following.py:97-103) -- while the fusion modules stay the fp32 oracle: the reference CLASS's own bf16 drift, the
+    same-precision comparator of the full-size bf16 legs."""
     vis, _ = O.otter_encode_vision(p, spec, vision_x)
     ml = np.asarray(ids) == spec.media_token_id
     hooks = []
@@ -70,7 +74,10 @@ def otter_llama_forward(hf, p: dict, spec: O.OtterSpec, vision_x: np.ndarray, id
         if spec.has_xattn(i):
             hooks.append(layer.register_forward_pre_hook(make(i), with_kwargs=True))
     try:
-        with torch.no_grad():
+        import contextlib
+
+        ac = torch.autocast("cpu", dtype=torch.bfloat16) if autocast_bf16 else contextlib.nullcontext()
+        with torch.no_grad(), ac:
             out = hf(input_ids=torch.from_numpy(np.asarray(ids)), labels=None if labels is None else torch.from_numpy(np.asarray(labels)))
     finally:
         for h in hooks:

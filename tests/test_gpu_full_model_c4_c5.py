@@ -5,7 +5,8 @@ C4  OTTER-Video-LLaMA7B: the 32-layer model bench.py --config c4 times (LLaMA-7B
     prompt, against tests/_host_ref.py on the host: transformers' LlamaForCausalLM in fp32 (the class the reference instantiates,
     modeling_otter.py:54,759-767; xformers_model/llama.py:286-327 is its in-repo restatement) with the numpy oracle's gated blocks hooked in
     front of the decoder layers, fed by the oracle's CLIP + perceiver (that composition is pinned against the reference's own tiny C4 model,
-    tests/test_llama_host.py).  fp32 parity mode: logits rtol <= 1e-3 (north star), loss 1e-4; bf16 production mode: reported and bounded.
+    tests/test_llama_host.py).  fp32 parity mode: logits rtol <= 1e-3 (north star), loss 1e-4; bf16 production mode: reported, and bounded by 1.5 x the
+    drift of the reference's own class under CPU bf16 autocast on the same model and batch (a random-init LLaMA amplifies bf16 rounding).
 C5  OtterHD / Fuyu-8B at full depth (36 Persimmon layers, 9.4 B parameters), one 1080 x 1080 image as 36 x (36 patches + newline) = 1332
     positions + a text tail (bench.py --config c5's sequence), logits + loss against tests/_host_ref.fuyu_forward on the host: transformers'
     PersimmonForCausalLM in fp32 (fuyu/modeling_persimmon.py:286-310 restates it) behind the reference's patch-embedding scatter
@@ -90,9 +91,21 @@ def test_c4_video_llama7b_full_size_logits_and_loss_vs_host_reference():
     srt = np.sort(ref["logits"][0], axis=-1)
     clear = (srt[:, -1] - srt[:, -2]) > 0.05 * np.abs(ref["logits"][0]).max(-1)
     rec16["argmax_agree_clear_margin"] = float((got16[0].argmax(-1)[clear] == ref["logits"][0].argmax(-1)[clear]).mean()) if clear.any() else 1.0
+    # Same-precision comparator.  A random-init LLaMA-7B amplifies bf16 rounding layer by layer (tools/c4_drift_by_layer.py,
+    # profiles/r05_c4_drift_by_layer.txt: the residual stream's per-row error grows from 7e-3 after layer 0 to 5.7e-2 after layer 31 --
+    # the MPT host of C2 stays flat at 8e-3), and so does the reference's own class: transformers' LlamaForCausalLM under
+    # torch.autocast("cpu", bfloat16), the mode the reference trains in, drifts 1.1e-2 / 3.0e-2 after 1 / 7 layers on the build container.
+    # So the bound is the reference class's own bf16 drift on THIS model and batch (decoder under CPU bf16 autocast, fusion modules fp32):
+    t0 = time.time()
+    ref16 = H.otter_llama_forward(hf, p, spec, vision_x.cpu().numpy(), ids.cpu().numpy(), labels.cpu().numpy(), autocast_bf16=True)
+    rec16["ref_bf16_logits_row_rel"] = G.row_rel_err(ref16["logits"][0], ref["logits"][0])
+    rec16["ref_bf16_cosine"] = G.cosine(ref16["logits"], ref["logits"])
+    rec16["ref_bf16_loss_rel"] = abs(ref16["loss"] - ref["loss"]) / abs(ref["loss"])
+    rec16["ref_bf16_forward_s"] = time.time() - t0
     G.record("full_model_c4_bf16", **rec16)
-    assert rec16["logits_row_rel"] < BF16_ROW_TOL and rec16["cosine"] > BF16_COS_MIN, rec16
-    assert rec16["loss_rel"] < BF16_LOSS_TOL, rec16
+    assert rec16["logits_row_rel"] <= 1.5 * rec16["ref_bf16_logits_row_rel"], rec16
+    assert 1.0 - rec16["cosine"] <= 1.5 * 1.5 * (1.0 - rec16["ref_bf16_cosine"]) + 1e-6, rec16         # (1 - cos ~ error^2 / 2)
+    assert rec16["loss_rel"] <= max(1.5 * rec16["ref_bf16_loss_rel"], BF16_LOSS_TOL), rec16
     assert rec16["argmax_agree_clear_margin"] == 1.0, rec16
 
 
