@@ -328,13 +328,17 @@ def test_flash_persistent_dkv_equals_per_block_kernel(ops, B, H, S, lens):
     assert relmax(f(outs[0][bsel, :, 2][:, :, hs]), rdv) < 2e-2
 
 
-def test_flash_backward_repeats_bit_for_bit_under_load(ops):
-    """300 launches of forward + backward at the benchmark's launch shape (persistent dK/dV form), part of them with unrelated traffic on a
-    second stream: every result equals the first one bit for bit -- a race between the DMA ring, the K / V staging area and the LDS
-    transpose of the persistent kernel would show as a run-to-run difference (tools/flash_stress.py runs thousands)."""
+@pytest.mark.parametrize("B,H,S,form", [(8, 32, 512, "persistent dK/dV (B x H = 256 workgroups, the benchmark's launch)"),
+                                        (3, 20, 448, "per-block dK/dV (B x H = 60: neither a multiple of the CU count nor 8 rounds)"),
+                                        (1, 24, 640, "per-block dK/dV, 5 key blocks")])
+def test_flash_backward_repeats_bit_for_bit_under_load(ops, B, H, S, form):
+    """300 launches of forward + backward, part of them with unrelated traffic on a second stream: every result equals the first one bit for
+    bit -- a race between the DMA ring, the K / V staging area and the LDS transpose would show as a run-to-run difference
+    (tools/flash_stress.py runs thousands).  Both forms of the dK/dV kernel: the persistent per-head one (the benchmark's launch) and the
+    per-block one, whose row-store epilogue stages dK / dV in the Q / dO ring -- ADVICE r4 found that the ring's last LDS-DMA pieces could
+    still be in flight there (fixed in round 5: every wave drains its own pieces before the barrier)."""
     from otter_amd.mpt import alibi_slopes
 
-    B, H, S = 8, 32, 512
     g = torch.Generator().manual_seed(77)
     qkv = (torch.randn(B, S, 3, H, 128, generator=g) * 0.8).to(torch.bfloat16).to(DEV)
     dout = torch.randn(B, S, H, 128, generator=g).to(torch.bfloat16).to(DEV)
