@@ -341,7 +341,8 @@ def _port_vs_reference(out):
     tools/stage_reference_loop.sh stage-models -> profiles/r04_cpu_baseline_calibration_gpu_node.json); the build container's 8-thread
     figure (profiles/r03_cpu_baseline_calibration.json) is the fallback.  The ratio is a committed constant, NOT measured in this run:
     its provenance (host threads of the calibration run vs the threads used now) is written next to it."""
-    for name, where in (("r04_cpu_baseline_calibration_gpu_node.json", "a GPU node of this pool"), ("r03_cpu_baseline_calibration.json", "the build container")):
+    for name, where in (("r05_cpu_baseline_calibration_gpu_node.json", "a GPU node of this pool (round 5)"), ("r04_cpu_baseline_calibration_gpu_node.json", "a GPU node of this pool"),
+                        ("r03_cpu_baseline_calibration.json", "the build container")):
         cal = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(cal):
             continue
@@ -352,7 +353,7 @@ def _port_vs_reference(out):
         out["reference_equivalent_value"] = round(out["value"] / r, 5)
         out["calibration"] = ("the reference's own modules (gated block, 6-layer perceiver, MPT block; fwd+bwd, fp32, torch CPU) ran the same sample in "
                               "%.2fx the time of the numpy port on %s: reference-equivalent rate = value / port_vs_reference" % (r, where))
-        out["calibration_provenance"] = {"file": "profiles/" + name, "measured_in_this_run": False, "calibration_host_threads": c.get("host_threads"),
+        out["calibration_provenance"] = {"file": "profiles/" + name, "measured_in_this_run": False, "calibration_host_threads": c.get("host_threads"), "calibration_numpy_blas_threads": c.get("numpy_blas_threads"),
                                          "calibration_host_logical_cpus": c.get("cpu_count"), "threads_used_now": out["cores"],
                                          "logical_cpus_now": os.cpu_count()}
         break

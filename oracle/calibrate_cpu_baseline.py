@@ -45,7 +45,13 @@ def main():
     torch.manual_seed(0)
     threads = torch.get_num_threads()
     D, Dv, T = 4096, 1024, 512
-    out = {"host_threads": threads, "cpu_count": os.cpu_count(), "sample": "1 pair: [1, 512, 4096] tokens, [1, 1, 64, 1024] latents / [1, 1, 1, 256, 1024] CLIP features, fp32"}
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = max([int(i.get("num_threads", 0)) for i in threadpool_info() if i.get("user_api") == "blas"] or [0])
+    except Exception:
+        blas = 0
+    out = {"host_threads": threads, "numpy_blas_threads": blas, "cpu_count": os.cpu_count(), "sample": "1 pair: [1, 512, 4096] tokens, [1, 1, 64, 1024] latents / [1, 1, 1, 256, 1024] CLIP features, fp32"}
     r = np.random.default_rng(0)
 
     # ---- gated cross-attention block ----
