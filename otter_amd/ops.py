@@ -17,13 +17,15 @@ _IDENT = RowMap(0, 0, 0)
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device (stream-ordered reuse: everything runs on torch's current stream)."""
+    """Grow-only scratch buffer per (device, stream): reuse is ordered by the stream the kernels are launched on (torch's current stream).
+    Keyed by the stream since round 5: the fusion modules launch on side streams too (functional._SideStream), and two kernels on two
+    streams must never share one scratch buffer."""
 
     def __init__(self):
         self.bufs = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = (device.type, device.index)
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         b = self.bufs.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
