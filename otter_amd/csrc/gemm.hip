@@ -534,13 +534,28 @@ __device__ __forceinline__ void park_stripe(float* __restrict__ blk, const AgprA
 #undef PARK_AGPR_STRIPE
 #undef PARK_AGPR_BLOCK
 
-template <int EPI, bool CBF16, bool INBF16, int NS, typename ACC>
+// HASIN (round 5): whether the tail reads a global input (accumulate / residual / aux) is a TEMPLATE parameter.  As a run-time flag the
+// compiler had to keep the waits of the input prefetch on every path: `s_waitcnt vmcnt(7)` in front of each store of a tail that had
+// issued no load at all -- and on gfx9 vmcnt counts stores, so a plain-store tail never had more than 7 stores per wave in flight
+// (7 KB per ~1.5 us of write latency = the "9.3 bytes per cycle and CU" that bounded the bf16 store tail).
+template <int EPI, bool CBF16, bool INBF16, int NS, bool HASIN, typename ACC>
 __device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, const ACC& acc, float* __restrict__ blk4 /* NS stripes */,
-                                                  int64_t m_wave, int64_t n_wave, int lane, const void* ip, int64_t ild, bool has_in) {
+                                                  int64_t m_wave, int64_t n_wave, int lane, const void* ip, int64_t ild) {
     using T = TailShape<CBF16>;
+    constexpr bool has_in = HASIN;
+    static_assert(NS % 2 == 0, "the stripe loop handles two stripes per iteration (ping-pong input buffers)");
     float part = 0.f;
-    uint4 cur[T::NIT][2], nxt[T::NIT][2];
-    if (has_in) tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave, lane, cur);   // stripe 0
+    // Two input buffers used alternately, NO register copies between them (round 5): the former `cur = nxt` hand-over at the end of every
+    // stripe made the compiler wait for the just-issued loads -- s_waitcnt vmcnt(0) / vmcnt(1) once per stripe, i.e. a full drain of every
+    // outstanding load AND store (vmcnt counts stores on gfx9): the residual / gate-backward tails paid one store round trip per stripe
+    // (34-60 k cycles per tile).  Now a buffer is requested TWO stripes before it is consumed -- also on the loop's
+    // entry edge, which is what the compiler's wait-count merge at the loop header takes -- so the first wait of an iteration leaves 15
+    // younger operations in flight instead of draining the previous stripe's stores.
+    uint4 bufA[T::NIT][2], bufB[T::NIT][2];
+    if (has_in) {   // stripes 0 and 1 are requested up front: a buffer is always TWO stripes ahead of its use (see the wait counts above)
+        tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave, lane, bufA);
+        tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave + 64, lane, bufB);
+    }
 #pragma unroll
     for (int half = 0; half < 8 / NS; ++half) {
 #pragma unroll
@@ -550,14 +565,16 @@ __device__ __forceinline__ float tail_wave_full_t(const GemmArgs& g, float s, co
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-        for (int q = 0; q < NS; ++q) {
+        for (int q = 0; q < NS; q += 2) {
             const int st = half * NS + q;
-            if (has_in && st + 1 < 8)   // request the next stripe's input before this stripe's arithmetic
-                tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + ((st + 1) >> 1) * 32, n_wave + ((st + 1) & 1) * 64, lane, nxt);
-            part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk4 + q * (32 * EPI_LD), m_wave + (st >> 1) * 32, n_wave + (st & 1) * 64, lane, cur,
+            part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk4 + q * (32 * EPI_LD), m_wave + (st >> 1) * 32, n_wave + (st & 1) * 64, lane, bufA,
                                                          has_in);
-#pragma unroll
-            for (int it = 0; it < T::NIT; ++it) { cur[it][0] = nxt[it][0]; cur[it][1] = nxt[it][1]; }
+            if (has_in && st + 2 < 8)
+                tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + ((st + 2) >> 1) * 32, n_wave + ((st + 2) & 1) * 64, lane, bufA);
+            part += tail_stripe_full<EPI, CBF16, INBF16>(g, s, blk4 + (q + 1) * (32 * EPI_LD), m_wave + ((st + 1) >> 1) * 32, n_wave + ((st + 1) & 1) * 64,
+                                                         lane, bufB, has_in);
+            if (has_in && st + 3 < 8)
+                tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + ((st + 3) >> 1) * 32, n_wave + ((st + 3) & 1) * 64, lane, bufB);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -570,10 +587,14 @@ __device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, cons
     const void* ip; int64_t ild; int idt;
     const bool has_in = tail_input<EPI>(g, ip, ild, idt);
     if constexpr (EPI == OTTER_EPI_GELU) {       // no global input at all: one instantiation
-        return tail_wave_full_t<EPI, CBF16, true, NS>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, false);
-    } else {
-        if (idt == OTTER_BF16) return tail_wave_full_t<EPI, CBF16, true, NS>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
-        return tail_wave_full_t<EPI, CBF16, false, NS>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild, has_in);
+        return tail_wave_full_t<EPI, CBF16, true, NS, false>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
+    } else if constexpr (EPI == OTTER_EPI_STORE) {   // input only when accumulating into C
+        if (!has_in) return tail_wave_full_t<EPI, CBF16, true, NS, false>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
+        if (idt == OTTER_BF16) return tail_wave_full_t<EPI, CBF16, true, NS, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
+        return tail_wave_full_t<EPI, CBF16, false, NS, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
+    } else {                                       // residual / aux kinds always read their input
+        if (idt == OTTER_BF16) return tail_wave_full_t<EPI, CBF16, true, NS, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
+        return tail_wave_full_t<EPI, CBF16, false, NS, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
     }
 }
 
