@@ -15,8 +15,9 @@ km = sys.argv[2] if len(sys.argv) > 2 else "0"
 M, N, Kd = 4096, 16384, 4096
 NSET = 8
 bf = torch.bfloat16
-As = [(torch.randn(M, Kd, device="cuda") * 0.05).to(bf) for _ in range(NSET)]
-Bs = [(torch.randn(N, Kd, device="cuda") * 0.05).to(bf) for _ in range(NSET)]
+AMP = float(os.environ.get("AMP", "0.05"))      # AMP=0: zero operands (no data-dependent power: is the K loop bound by the clock or by the memory path?)
+As = [(torch.randn(M, Kd, device="cuda") * AMP).to(bf) for _ in range(NSET)]
+Bs = [(torch.randn(N, Kd, device="cuda") * AMP).to(bf) for _ in range(NSET)]
 if km == "ab":
     As = [a.t().contiguous() for a in As]
     Bs = [b.t().contiguous() for b in Bs]
