@@ -132,3 +132,77 @@ def fuyu_forward(hf_lm, fuyu_state: dict, ids, patches, patch_indices, labels=No
         am = None if attention_mask is None else torch.as_tensor(np.asarray(attention_mask))
         out = hf_lm(inputs_embeds=emb, attention_mask=am, labels=None if labels is None else torch.as_tensor(np.asarray(labels)))
     return dict(logits=out.logits.float().numpy(), loss=None if labels is None else float(out.loss))
+
+
+def otter_llama_forward_backward(hf, p: dict, spec: O.OtterSpec, vision_x: np.ndarray, ids: np.ndarray, labels: np.ndarray,
+                                 layer_prefix="lang_encoder.model.layers.", autocast_bf16: bool = False):
+    """Forward with loss AND backward of the composed model on the host: gradients of the reference recipe's trainable set for a LLaMA host
+    (modeling_otter.py:897-907: perceiver.*, *.gated_cross_attn_layer.*, the input embedding and lm_head).  The decoder's backward is
+    transformers' own autograd graph (input gradient through every frozen layer, weight gradients of embed_tokens / lm_head); each gated block
+    is an autograd Function around the oracle's forward / hand-derived backward (its parameter gradients are collected on the side), the
+    conditioned media tensor is one leaf shared by the eight blocks, and the resampler's backward is the oracle's.  Pinned against the
+    reference's own gradients (tests/golden/otter_tiny_llama.npz) by tests/test_llama_host.py.
+    Returns dict(loss, logits, grads={state-dict name: ndarray})."""
+    import contextlib
+
+    vis, cv = O.otter_encode_vision(p, spec, vision_x)
+    ml = np.asarray(ids) == spec.media_token_id
+    vis_t = torch.from_numpy(np.ascontiguousarray(vis)).requires_grad_(True)
+    grads = {}
+
+    class _Gated(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, h, media, pre):
+            y, c = O.gated_xattn_block_fwd(p, pre, h.detach().numpy().astype(np.float32), media.detach().numpy(), ml, True, spec.immediate, spec.xattn_heads)
+            ctx.c, ctx.pre = c, pre
+            return torch.from_numpy(np.ascontiguousarray(y)).to(h.dtype)
+
+        @staticmethod
+        def backward(ctx, dy):
+            dx, dmedia, gi = O.gated_xattn_block_bwd(p, ctx.pre, dy.detach().float().numpy(), ctx.c)
+            grads.update(gi)
+            return torch.from_numpy(np.ascontiguousarray(dx)).to(dy.dtype), torch.from_numpy(np.ascontiguousarray(dmedia)), None
+
+    hooks = []
+
+    def make(i):
+        pre = layer_prefix + "%d.gated_cross_attn_layer." % i
+
+        def hook(mod, args, kwargs):
+            h = args[0] if args else kwargs["hidden_states"]
+            t = _Gated.apply(h, vis_t, pre)
+            if args:
+                return (t,) + tuple(args[1:]), kwargs
+            kwargs = dict(kwargs)
+            kwargs["hidden_states"] = t
+            return args, kwargs
+
+        return hook
+
+    for q in hf.parameters():
+        q.requires_grad_(False)
+        q.grad = None
+    hf.model.embed_tokens.weight.requires_grad_(True)
+    hf.lm_head.weight.requires_grad_(True)
+    for i, layer in enumerate(hf.model.layers):
+        if spec.has_xattn(i):
+            hooks.append(layer.register_forward_pre_hook(make(i), with_kwargs=True))
+    try:
+        ac = torch.autocast("cpu", dtype=torch.bfloat16) if autocast_bf16 else contextlib.nullcontext()
+        with ac:
+            out = hf(input_ids=torch.from_numpy(np.asarray(ids)), labels=torch.from_numpy(np.asarray(labels)))
+        out.loss.backward()
+    finally:
+        for h in hooks:
+            h.remove()
+    _, gp = O.perceiver_resampler_bwd(p, "perceiver.", vis_t.grad.numpy(), cv)
+    grads.update(gp)
+    lm_prefix = layer_prefix[: layer_prefix.index("model.layers.")]
+    grads[lm_prefix + "model.embed_tokens.weight"] = hf.model.embed_tokens.weight.grad.float().numpy().copy()
+    grads[lm_prefix + "lm_head.weight"] = hf.lm_head.weight.grad.float().numpy().copy()
+    res = dict(loss=float(out.loss), logits=out.logits.detach().float().numpy(), grads=grads)
+    hf.model.embed_tokens.weight.grad = None
+    hf.lm_head.weight.grad = None
+    for q in hf.parameters():
+        q.requires_grad_(False)
+    return res

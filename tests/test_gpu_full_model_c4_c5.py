@@ -5,7 +5,8 @@ C4  OTTER-Video-LLaMA7B: the 32-layer model bench.py --config c4 times (LLaMA-7B
     prompt, against tests/_host_ref.py on the host: transformers' LlamaForCausalLM in fp32 (the class the reference instantiates,
     modeling_otter.py:54,759-767; xformers_model/llama.py:286-327 is its in-repo restatement) with the numpy oracle's gated blocks hooked in
     front of the decoder layers, fed by the oracle's CLIP + perceiver (that composition is pinned against the reference's own tiny C4 model,
-    tests/test_llama_host.py).  fp32 parity mode: logits rtol <= 1e-3 (north star), loss 1e-4; bf16 production mode: reported, and bounded by 1.5 x the
+    tests/test_llama_host.py).  Forward AND the training step (TrainStep's composed backward vs transformers' autograd + the oracle's
+    hand-derived backward of the fusion modules).  fp32 parity mode: logits rtol <= 1e-3 (north star), loss 1e-4, gradients 1e-3; bf16 production mode: reported, and bounded by 1.5 x the
     drift of the reference's own class under CPU bf16 autocast on the same model and batch (a random-init LLaMA amplifies bf16 rounding).
 C5  OtterHD / Fuyu-8B at full depth (36 Persimmon layers, 9.4 B parameters), one 1080 x 1080 image as 36 x (36 patches + newline) = 1332
     positions + a text tail (bench.py --config c5's sequence), logits + loss against tests/_host_ref.fuyu_forward on the host: transformers'
@@ -40,7 +41,8 @@ def _free_host_gb():
     return psutil.virtual_memory().available / 2**30
 
 
-def test_c4_video_llama7b_full_size_logits_and_loss_vs_host_reference():
+@pytest.fixture(scope="module")
+def c4():
     import bench
 
     if _free_host_gb() < 80:
@@ -61,13 +63,22 @@ def test_c4_video_llama7b_full_size_logits_and_loss_vs_host_reference():
          if v.is_floating_point() and (k.startswith("vision_encoder.") or k.startswith("perceiver.") or ".gated_cross_attn_layer." in k)}
     spec = O.OtterSpec(n_layers=32, d_model=4096, n_heads=32, max_seq_len=2048, cross_attn_every_n_layers=4, media_token_id=model.media_token_id,
                        clip_heads=16, clip_patch=14)
+    print("[c4] model + host copies in %.0f s" % (time.time() - t0), flush=True)
+    yield dict(model=model, hf=hf, p=p, spec=spec, bench=bench, memo={})
+    del model, hf, p
+    torch.cuda.empty_cache()
+
+
+def test_c4_video_llama7b_full_size_logits_and_loss_vs_host_reference(c4):
+    model, hf, p, spec, bench = c4["model"], c4["hf"], c4["p"], c4["spec"], c4["bench"]
+    assert next(q for q in model.parameters() if not q.requires_grad).dtype == torch.float32, "the fp32 legs run first"
     vision_x, ids, mask, labels, _ = bench.synth_batch(model, 1, 64, DEV, seed=777, frames=8)
     assert vision_x.shape[:3] == (1, 1, 8) and int((ids == model.media_token_id).sum()) == 1
-    print("[c4] model + host copies in %.0f s" % (time.time() - t0), flush=True)
     t0 = time.time()
     ref = H.otter_llama_forward(hf, p, spec, vision_x.cpu().numpy(), ids.cpu().numpy(), labels.cpu().numpy())
     t_ref = time.time() - t0
     print("[c4] host reference forward %.1f s (%d host threads)" % (t_ref, os.cpu_count()), flush=True)
+    c4["memo"]["fwd"] = (vision_x, ids, mask, labels, ref)
     # ---- fp32 parity mode
     with torch.no_grad():
         out = model(vision_x=vision_x, lang_x=ids, attention_mask=mask, labels=labels)
@@ -78,7 +89,94 @@ def test_c4_video_llama7b_full_size_logits_and_loss_vs_host_reference():
     assert rec["logits_rel_max"] < 1e-3 and rec["logits_row_rel"] < 1e-3, rec          # north_star: logits rtol <= 1e-3
     assert rec["loss_rel"] < 1e-4, rec
     assert np.array_equal(got[0].argmax(-1), ref["logits"][0].argmax(-1)) or rec["logits_row_rel"] < 1e-5   # greedy choice of every position
-    # ---- bf16 production mode (the kernels bench.py --config c4 runs)
+
+
+def _c4_train_step(c4, bf16):
+    """otter_amd.train.TrainStep (bench.py --config c4's step) on a 2-sample x 64-token x 8-frame batch; returns (step, snapshot, loss)."""
+    from otter_amd.train import TrainStep
+
+    model, bench = c4["model"], c4["bench"]
+    if "train_batch" not in c4["memo"]:
+        c4["memo"]["train_batch"] = bench.synth_batch(model, 2, 64, DEV, seed=2024, frames=8)[:4]
+    vision_x, ids, mask, labels = c4["memo"]["train_batch"]
+    snap = {n: q.detach().clone() for n, q in model.named_parameters() if q.requires_grad}
+    model.train()
+    step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16 if bf16 else None)
+    assert step.hip_optimizer and step.reducer is None
+    loss = float(step(vision_x, ids, mask, labels))
+    torch.cuda.synchronize()
+    model.eval()
+    return step, snap, loss
+
+
+def _c4_host_grads(c4, autocast_bf16=False):
+    key = "grads_bf16" if autocast_bf16 else "grads_fp32"
+    if key not in c4["memo"]:
+        vision_x, ids, mask, labels = c4["memo"]["train_batch"]
+        t0 = time.time()
+        c4["memo"][key] = H.otter_llama_forward_backward(c4["hf"], c4["p"], c4["spec"], vision_x.cpu().numpy(), ids.cpu().numpy(), labels.cpu().numpy(),
+                                                         autocast_bf16=autocast_bf16)
+        print("[c4] host forward + backward (%s) %.1f s" % ("decoder under CPU bf16 autocast" if autocast_bf16 else "fp32", time.time() - t0), flush=True)
+    return c4["memo"][key]
+
+
+def _c4_grad_errors(model, ref_grads):
+    """{name: relative l2 error} of the model's .grad against the host gradients, every trainable tensor; gate scalars against their group scale."""
+    from tests.test_gpu_full_model import _tensor_err
+
+    prm = {n: q for n, q in model.named_parameters() if q.requires_grad}
+    assert sorted(prm) == sorted(ref_grads), set(prm) ^ set(ref_grads)
+    gates = [n for n in prm if ref_grads[n].size == 1]
+    scale = max(abs(float(ref_grads[n].reshape(-1)[0])) for n in gates)
+    err = {}
+    for n, q in prm.items():
+        assert q.grad is not None, n
+        if n in gates:
+            err[n] = abs(float(q.grad.reshape(-1)[0]) - float(ref_grads[n].reshape(-1)[0])) / scale
+        else:
+            err[n] = _tensor_err(q.grad.float().cpu().numpy(), ref_grads[n])[0]
+    return err
+
+
+def _restore(model, snap):
+    with torch.no_grad():
+        for n, q in model.named_parameters():
+            if n in snap:
+                q.copy_(snap[n])
+    for q in model.parameters():
+        q.grad = None
+    torch.cuda.empty_cache()
+
+
+def test_c4_full_size_training_step_fp32_vs_host_backward(c4):
+    """The C4 TRAINING step at full size (round 5): TrainStep (composed backward through the LLaMA host's RMSNorm / RoPE / SwiGLU / flash or fp32
+    attention dgrad, the 8 gated blocks, the resampler on 2 112 keys with frame embeddings, the un-tied input embedding and lm_head) against
+    tests/_host_ref.otter_llama_forward_backward -- transformers' own autograd through LlamaForCausalLM + the oracle's hand-derived backward of
+    the fusion modules, pinned on the reference's tiny C4 gradients.  fp32 parity mode, every trainable tensor (96 of them) within 1e-3."""
+    model = c4["model"]
+    assert next(q for q in model.parameters() if not q.requires_grad).dtype == torch.float32, "the fp32 legs run first"
+    step, snap, loss = _c4_train_step(c4, bf16=False)
+    try:
+        ref = _c4_host_grads(c4)
+        err = _c4_grad_errors(model, ref["grads"])
+        worst = max(err.items(), key=lambda kv: kv[1])
+        norm_hip = float(step.optimizer.last_norm.cpu()[0])
+        norm_ref = float(np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ref["grads"].values())))
+        G.record("full_model_c4_train_step_fp32", loss=loss, loss_ref=ref["loss"], worst_grad_rel_l2=worst[1], worst_grad=worst[0], tensors=float(len(err)),
+                 grad_norm=norm_hip, grad_norm_ref=norm_ref)
+        assert abs(loss - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (loss, ref["loss"])
+        assert worst[1] < 1e-3, worst
+        assert abs(norm_hip - norm_ref) <= 1e-3 * norm_ref, (norm_hip, norm_ref)
+    finally:
+        del step
+        _restore(model, snap)
+
+
+def test_c4_video_llama7b_full_size_bf16_within_the_reference_class_drift(c4):
+    """bf16 production mode (the kernels bench.py --config c4 runs), forward: reported, and bounded by 1.5 x the drift of the reference's own
+    class under CPU bf16 autocast on the same model and batch."""
+    model, hf, p, spec = c4["model"], c4["hf"], c4["p"], c4["spec"]
+    vision_x, ids, mask, labels, ref = c4["memo"]["fwd"]
     for q in model.parameters():
         if not q.requires_grad:
             q.data = q.data.to(torch.bfloat16)
@@ -107,6 +205,38 @@ def test_c4_video_llama7b_full_size_logits_and_loss_vs_host_reference():
     assert 1.0 - rec16["cosine"] <= 1.5 * 1.5 * (1.0 - rec16["ref_bf16_cosine"]) + 1e-6, rec16         # (1 - cos ~ error^2 / 2)
     assert rec16["loss_rel"] <= max(1.5 * rec16["ref_bf16_loss_rel"], BF16_LOSS_TOL), rec16
     assert rec16["argmax_agree_clear_margin"] == 1.0, rec16
+
+
+def test_c4_full_size_training_step_bf16_within_the_reference_class_drift(c4):
+    """bf16 production mode, the training step: gradients of TrainStep vs the fp32 host backward, reported per tensor; bounded, as a
+    root-mean-square over the 96 trainable tensors, by 1.5 x the same figure of the reference's own class (transformers' LlamaForCausalLM under
+    CPU bf16 autocast + the fp32 oracle blocks) -- a random-init LLaMA-7B amplifies bf16 rounding, identically in the reference."""
+    model = c4["model"]
+    assert next(q for q in model.parameters() if not q.requires_grad).dtype == torch.bfloat16, "runs after the bf16 forward leg"
+    from tests.test_gpu_full_model import _tensor_err
+
+    step, snap, loss = _c4_train_step(c4, bf16=True)
+    try:
+        ref = _c4_host_grads(c4)
+        ref16 = _c4_host_grads(c4, autocast_bf16=True)
+        err = _c4_grad_errors(model, ref["grads"])
+        gates = [n for n in err if ref["grads"][n].size == 1]
+        scale = max(abs(float(ref["grads"][n].reshape(-1)[0])) for n in gates)
+        err_ref = {n: (abs(float(ref16["grads"][n].reshape(-1)[0]) - float(ref["grads"][n].reshape(-1)[0])) / scale if n in gates
+                       else _tensor_err(ref16["grads"][n], ref["grads"][n])[0]) for n in err}
+        rms = float(np.sqrt(np.mean([v ** 2 for v in err.values()])))
+        rms_ref = float(np.sqrt(np.mean([v ** 2 for v in err_ref.values()])))
+        worst = max(err.items(), key=lambda kv: kv[1])
+        worst_ratio = max((err[n] / max(err_ref[n], 5e-3), n) for n in err)
+        G.record("full_model_c4_train_step_bf16", loss=loss, loss_ref=ref["loss"], loss_ref_bf16=ref16["loss"], grad_rms_hip=rms, grad_rms_ref_bf16=rms_ref,
+                 worst_grad_rel_l2=worst[1], worst_grad=worst[0], worst_ratio=worst_ratio[0], worst_ratio_tensor=worst_ratio[1],
+                 tensors_below_reference=float(sum(1 for n in err if err[n] <= err_ref[n])), tensors=float(len(err)))
+        assert rms <= 1.5 * rms_ref, (rms, rms_ref)
+        assert worst_ratio[0] <= 3.0, worst_ratio
+        assert abs(loss - ref["loss"]) <= max(1.5 * abs(ref16["loss"] - ref["loss"]), BF16_LOSS_TOL * abs(ref["loss"])), (loss, ref["loss"], ref16["loss"])
+    finally:
+        del step
+        _restore(model, snap)
 
 
 def test_c5_fuyu8b_full_depth_logits_and_loss_vs_transformers_fp32():

@@ -107,3 +107,28 @@ def test_host_reference_composition_reproduces_the_reference_fixture():
     out = H.otter_llama_forward(hf, sd, spec, vision_x, ids, labels)
     assert G.rel_err(out["logits"], gold["logits"]) < 2e-4
     assert abs(out["loss"] - float(gold["loss"])) < 2e-4 * abs(float(gold["loss"]))
+
+
+def test_host_reference_backward_reproduces_the_reference_gradients():
+    """tests/_host_ref.otter_llama_forward_backward -- the host side of the full-size C4 TRAINING-STEP parity test -- against the gradients of
+    the reference's own tiny OTTER-over-LLaMA model (tests/golden/otter_tiny_llama.npz: every trainable tensor, incl. frame embeddings, the
+    input embedding and lm_head)."""
+    from oracle import otter_oracle as O
+    from oracle import synth
+    from oracle.gen_golden import tiny_llama_configs
+    from tests import _golden as G
+    from tests import _host_ref as H
+
+    m = G.meta()["otter_tiny_llama"]
+    gold = G.load("otter_tiny_llama")
+    sd = synth.state_dict_for(m["seed"], {k: tuple(v) for k, v in m["state_dict_shapes"].items()})
+    text_cfg, _ = tiny_llama_configs()
+    hf = H.new_hf_llama(text_cfg)
+    H.load_decoder_weights(hf, {k[len("lang_encoder."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("lang_encoder.")})
+    t = synth.TINY
+    spec = O.OtterSpec(4, 64, 4, 64, 2, t["media_token_id"], t["clip_heads"], t["patch"])
+    vision_x, ids, mask, labels = synth.tiny_batch(m["seed"], F=3)
+    out = H.otter_llama_forward_backward(hf, sd, spec, vision_x, ids, labels)
+    assert abs(out["loss"] - float(gold["loss"])) < 2e-4 * abs(float(gold["loss"]))
+    assert sorted(out["grads"]) == m["trainable"]
+    G.check_grads(gold, out["grads"], 5e-4)
