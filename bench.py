@@ -80,7 +80,61 @@ def machine_calibration(device):
     res["hbm_copy_tbps"] = round(4 * 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e12, 3)   # bytes read + bytes written
     res["compute_units"] = n_wg
     del a, b
+    # The memory path as the GEMM sees it: the FFN-shape product on ZERO operands runs at the un-throttled clock, so what it takes beyond
+    # 256 K-tiles x 2048 cycles per CU is the part of the LDS-DMA's loaded latency that the two-stage prefetch does not cover plus four
+    # prologue + tail pairs (one K-tile = 2048 / f + ~235 ns on the faster boxes).  Boxes whose MFMA probe and copy
+    # rate are within 2 % of each other differ by 11 % on the real kernel; this figure is the one that moves with them.
+    try:
+        from otter_amd import ops as _ops
+
+        M, N, Kd = 4096, 16384, 4096
+        za = torch.zeros(M, Kd, dtype=torch.bfloat16, device=device)
+        zb = torch.zeros(N, Kd, dtype=torch.bfloat16, device=device)
+        zc = torch.empty(M, N, dtype=torch.bfloat16, device=device)
+        for _ in range(3):
+            _ops.gemm_nt(za, zb, out=zc)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            _ops.gemm_nt(za, zb, out=zc)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 8 * 1e3
+        f = res["zero_operands"]["clock_ghz"]
+        res["ffn_gemm_zero_operands_us"] = round(us, 1)
+        res["exposed_latency_ns_per_ktile"] = round((us * 1e3 - 4 * 17000.0 / f) / 256.0 - 2048.0 / f, 1)
+        del za, zb, zc
+    except Exception as ex:      # (a calibration extra must never cost the bench line)
+        res["ffn_gemm_zero_operands_us"] = None
+        res["calibration_note"] = "zero-operand GEMM probe failed: %r" % (ex,)
     return res
+
+
+def in_step_gemm_clock(one_step):
+    """Shader clock of an FFN-shape GEMM launch INSIDE a training step: one extra (untimed) step with the kernel's tile-phase stamps switched on
+    (otter_gemm_set_debug bit 64: s_memtime and the 100 MHz wall clock at the tile boundaries of workgroup 0); the stamps that remain are those
+    of the step's last large-grid launch.  The probes of machine_calibration run for ~0.1 s after the steps; on some boxes of the pool the
+    sustained step runs its GEMMs hundreds of MHz below what those short probes reach -- this is the figure that shows it."""
+    import ctypes
+
+    from otter_amd import _capi as K_
+
+    lib = K_.lib()
+    K_.check(lib.otter_gemm_set_debug(64), "gemm_set_debug")
+    try:
+        one_step()
+        torch.cuda.synchronize()
+    finally:
+        K_.check(lib.otter_gemm_set_debug(0), "gemm_set_debug")
+    buf = np.zeros(512, dtype=np.uint64)
+    K_.check(lib.otter_gemm_read_timeline(buf.ctypes.data_as(ctypes.c_void_p), 512), "gemm_read_timeline")
+    t = buf.reshape(2, 4, 8, 8).astype(np.int64)[0, 0]          # workgroup 0, wave 0: [tile][mark]
+    tiles = [i for i in range(8) if t[i, 0] > 0 and t[i, 4] > t[i, 0] and t[i, 6] > t[i, 5]]
+    if not tiles:
+        return None
+    cyc = float(sum(t[i, 4] - t[i, 0] for i in tiles))
+    ticks = float(sum(t[i, 6] - t[i, 5] for i in tiles))
+    return {"clock_ghz": round(cyc / ticks * 0.1, 3), "tiles": len(tiles), "cycles_per_tile": round(cyc / len(tiles)), "us_per_tile": round(ticks / len(tiles) * 0.01, 1)}
 
 
 def apply_calibration(out, roof, cal):
@@ -712,7 +766,13 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not n_occ:
-            apply_calibration(out, roof, machine_calibration(device))
+            cal = machine_calibration(device)
+            try:
+                cal["in_step_gemm"] = in_step_gemm_clock(one_step)      # (one more optimizer step, after everything that is reported)
+            except Exception as ex:
+                cal["in_step_gemm"] = None
+                cal["calibration_note"] = (cal.get("calibration_note", "") + " in-step clock failed: %r" % (ex,)).strip()
+            apply_calibration(out, roof, cal)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(T, args.config)
         print(json.dumps(out), flush=True)

@@ -405,7 +405,8 @@ int otter_adamw_step(const otter_adamw_tensor* tensors, const int32_t* blk_tenso
 int otter_prof_arm_gemm(int64_t M, int64_t N, int64_t K, int max_events);
 /* Diagnostics: with otter_gemm_set_debug bit 64 set, the one-wave-per-SIMD bf16 kernels (variants 18-20) record shader-clock
  * timestamps at their tile-phase boundaries for two blocks; this copies the first n of the 512 uint64 slots
- * ([block 2][wave 4][tile 8][mark 8]: 0 tile start, 1 prologue done, 2 K loop done, 3 tail done, 4 tile end) to the host. */
+ * ([block 2][wave 4][tile 8][mark 8]: 0 tile start, 1 prologue done, 2 K loop done, 3 tail done, 4 tile end; the large-grid kernel also
+ * stamps the 100 MHz wall clock at tile start / end in marks 5 / 6: the shader clock of that very launch) to the host. */
 int otter_gemm_read_timeline(unsigned long long* out, int n);
 int otter_prof_disarm(void);
 int otter_prof_collect(int* count, double* total_ms);

@@ -26,7 +26,8 @@ thread_local char g_otter_err[512] = {0};
 
 // Diagnostics (otter_gemm_set_debug bit 64 + otter_gemm_read_timeline): tile-phase timestamps (s_memtime, shader cycles) of
 // the one-wave-per-SIMD kernels, blocks 0 and 131, every wave, the first 8 tiles of the block:
-// [block sel 2][wave 4][tile 8][mark 8] -- marks: 0 tile start, 1 prologue done, 2 K loop done, 3 tail done, 4 tile end.
+// [block sel 2][wave 4][tile 8][mark 8] -- marks: 0 tile start, 1 prologue done, 2 K loop done, 3 tail done, 4 tile end; variant 26 also
+// stamps the 100 MHz wall clock (s_memrealtime) at tile start (mark 5) and tile end (mark 6): cycles / ticks = the shader clock of that launch.
 __device__ unsigned long long g_gemm_timeline[2 * 4 * 8 * 8];
 
 namespace {
@@ -1490,7 +1491,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #define TMARK(K_)                                                                                                         \
     do {                                                                                                                  \
         if ((g.dbg & 64) && (blockIdx.x == 0 || blockIdx.x == 131) && lane == 0 && tcount < 8)                            \
+        {                                                                                                                 \
             g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + (K_)] = __builtin_amdgcn_s_memtime();  \
+            if ((K_) == 0 || (K_) == 4)   /* marks 5 / 6: the 100 MHz wall clock at tile start / end -> shader clock of THIS launch */ \
+                g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + ((K_) == 0 ? 5 : 6)] = wall_clock64();  \
+        }                                                                                                                 \
     } while (0)
     int tcount = 0;
 #define SB() __builtin_amdgcn_sched_barrier(0)
