@@ -244,3 +244,25 @@ def test_train_step_scopes_grid_mode_and_drops_stale_embedding_rows():
         ops.gemm_grid_mode(7)
     step.close()
     assert ops._grid_mode == K.GRID_DEFAULT
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_host_and_names_its_provenance():
+    """bench.py's `cpu_baseline` object (tier brief section 4): the numpy oracle timed per component on the host cores -- the only place outside
+    tests/ and smoke() that may touch oracle/.  A short sequence keeps it to seconds; checked: the fields the JSON line carries, `cores` = the
+    BLAS threads actually used (not the logical CPU count by default), and the calibration ratio's provenance (a committed constant measured on
+    a GPU node, flagged as not measured in this run)."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    b = bench.cpu_baseline(T=64, config="c2")
+    assert b["kind"] == "port" and b["unit"] == "pairs/s" and b["value"] > 0
+    assert 1 <= b["cores"] <= b["host_logical_cpus"] == os.cpu_count()
+    assert "8*gated + 32*lm + perceiver + 24*clip + unembed" in b["sample"]
+    prov = b["calibration_provenance"]
+    assert prov["measured_in_this_run"] is False and os.path.exists(os.path.join(root, prov["file"]))
+    assert abs(b["reference_equivalent_value"] - b["value"] / b["port_vs_reference"]) < 1e-4 * max(b["value"], 1e-9) + 1e-5
+    assert prov["threads_used_now"] == b["cores"]
