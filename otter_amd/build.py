@@ -111,7 +111,8 @@ def build_flash_timing(verbose: bool = True) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "otter_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "otter_hip.h"),
+            os.path.join(CSRC, "gemm_t4_ktile.inc")]   # (generated K-tile schedules of gemm.hip: tools/gen/gemm_t4_schedule.py inc)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     if not force and _newer(LIB, srcs + hdrs):
         return LIB

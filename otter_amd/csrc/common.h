@@ -119,6 +119,75 @@ __device__ __forceinline__ void gelu_cdf_pdf(float u, float& cdf, float& pdf) {
     pdf = 0.39894228040143267794f * e;
 }
 
+// Phi(u) for the bf16-output tails of the GEMM (round 6), two elements per instruction: Phi(u) - 1/2 is odd, = u * Q(u^2) with a degree-8
+// minimax Q on |u| <= 4.2 (tools/gen/gelu_poly.py), u clamped to +-4.2 where the fit is scaled to reach exactly +-1/2 -- so the result
+// saturates at 0 / 1 instead of drifting.  |error| <= 1.5e-5 absolute in fp32 Horner form (bf16's half-ulp at 1 is 2e-3); 2 v_med3 + 11
+// packed fp32 instructions per PAIR against 15 scalar ones + rcp + exp per ELEMENT for gelu_cdf_pdf: with one wave per SIMD every
+// instruction of the tail is an issue slot (~4 cycles), and the GELU tail was 256 elements x ~17 slots per lane = two thirds of its 28 k cycles.
+typedef __attribute__((ext_vector_type(2))) float otter_f2;
+// NP independent pairs at once, the Horner levels in the OUTER loop: consecutive instructions belong to different pairs, so no level waits for
+// the one before it (written pair by pair, hipcc kept each pair's eleven-deep dependent chain together -- s_nop between every two v_pk_fma --
+// and the tail took as long as with the scalar form).  Returns Phi(u[p]); uc = the clamped arguments.
+template <int NP>
+__device__ __forceinline__ void gelu_cdf_fast(const otter_f2 (&u)[NP], otter_f2 (&cdf)[NP]) {
+    otter_f2 uc[NP], s[NP], q[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        uc[p].x = __builtin_amdgcn_fmed3f(u[p].x, -4.2f, 4.2f);
+        uc[p].y = __builtin_amdgcn_fmed3f(u[p].y, -4.2f, 4.2f);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s[p] = uc[p] * uc[p];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) q[p] = s[p] * 5.998143648e-11f + -5.633387978e-09f;
+    constexpr float C[7] = {2.343703045e-07f, -5.760839940e-06f, 9.457554552e-05f, -1.114161452e-03f, 9.830248542e-03f, -6.636116654e-02f, 3.989122212e-01f};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) q[p] = q[p] * s[p] + C[k];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) cdf[p] = uc[p] * q[p] + 0.5f;
+}
+// GELU(v) of NE = 2 NP values
+template <int NE>
+__device__ __forceinline__ void gelu_fast(const float (&v)[NE], float (&o)[NE]) {
+    otter_f2 u[NE / 2], cdf[NE / 2];
+#pragma unroll
+    for (int p = 0; p < NE / 2; ++p) u[p] = otter_f2{v[2 * p], v[2 * p + 1]};
+    gelu_cdf_fast<NE / 2>(u, cdf);
+#pragma unroll
+    for (int p = 0; p < NE / 2; ++p) {
+        const otter_f2 r = u[p] * cdf[p];
+        o[2 * p] = r.x; o[2 * p + 1] = r.y;
+    }
+}
+// gate / GELU backward of NE values: o = s v GELU'(a) with GELU'(a) = Phi(a) + a phi(a) (the polynomial Phi + ONE v_exp_f32 per element for
+// the density), returns sum v GELU(a)
+template <int NE>
+__device__ __forceinline__ float gelu_bwd_fast(float sc, const float (&v)[NE], const float (&a)[NE], float (&o)[NE]) {
+    constexpr int NP = NE / 2;
+    otter_f2 a2[NP], v2[NP], cdf[NP], e[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { a2[p] = otter_f2{a[2 * p], a[2 * p + 1]}; v2[p] = otter_f2{v[2 * p], v[2 * p + 1]}; }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const otter_f2 arg = (a2[p] * a2[p]) * -0.72134752044448170368f;   // exp(-a^2 / 2) = exp2(-a^2 / (2 ln 2))
+        e[p].x = __builtin_amdgcn_exp2f(arg.x);
+        e[p].y = __builtin_amdgcn_exp2f(arg.y);
+    }
+    gelu_cdf_fast<NP>(a2, cdf);
+    otter_f2 part2 = {0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const otter_f2 grad = (a2[p] * e[p]) * 0.39894228040143267794f + cdf[p];
+        part2 = v2[p] * (a2[p] * cdf[p]) + part2;
+        const otter_f2 r = (v2[p] * sc) * grad;
+        o[2 * p] = r.x; o[2 * p + 1] = r.y;
+    }
+    return part2.x + part2.y;
+}
+
 // exact-erf GELU and its derivative (nn.GELU() default, approximate='none')
 __device__ __forceinline__ float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float u) {

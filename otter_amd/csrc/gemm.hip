@@ -49,6 +49,8 @@ struct GemmArgs {
     int wide;  // bf16 output and every tensor the fused tail touches allows 8-element accesses (N, ldc, ldc2, ldr, ldaux % 8 == 0)
     int ta, tb;  // operand A / B is K-major ([K rows][M or N columns]); variant 26 only (otter_gemm)
     int grid_mode;  // host side only: 0 = process default (otter_gemm_set_persistent), 1 = persistent grid, 2 = one workgroup per tile
+    int korder;  // cross-tile form of variant 26: K-tile order of a tile (bits 0-1 rotation by XCD / tile, bits 2-3 in-group permutation; see xt_tile);
+                 // bits 4-6: start phase step (units of 1024 cycles) between the four workgroup phases
 };
 
 __device__ __forceinline__ void load4(const void* p, int64_t idx, int dt, float (&v)[4]) {
@@ -86,6 +88,39 @@ __device__ __forceinline__ void store4(void* p, int64_t idx, int dt, const float
     }
 }
 
+// GELU of NE accumulator values / the GELU-backward of the gate-backward tail (o = s v GELU'(a), returns sum v GELU(a)).  bf16 results take
+// the packed polynomial Phi of common.h (gelu_cdf_fast2: |error| <= 1.5e-5, far inside bf16 rounding), fp32 results the A&S 7.1.26 form
+// (1.5e-7): every kernel and every tail flavour of this file goes through these two, so one launch shape gives one result.
+template <int NE>
+__device__ __forceinline__ void gelu_apply(bool fast, const float (&v)[NE], float (&o)[NE]) {
+    if (fast) {
+        gelu_fast<NE>(v, o);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            float cdf, pdf;
+            gelu_cdf_pdf(v[i], cdf, pdf);
+            o[i] = v[i] * cdf;
+        }
+    }
+}
+template <int NE>
+__device__ __forceinline__ float gelu_bwd_apply(bool fast, float s, const float (&v)[NE], const float (&a)[NE], float (&o)[NE]) {
+    float part = 0.f;
+    if (fast) {
+        part = gelu_bwd_fast<NE>(s, v, a, o);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {   // gelu and gelu' share the erf: one transcendental chain instead of two
+            float cdf, pdf;
+            gelu_cdf_pdf(a[i], cdf, pdf);
+            part += v[i] * (a[i] * cdf);
+            o[i] = s * v[i] * (cdf + a[i] * pdf);
+        }
+    }
+    return part;
+}
+
 // epilogue on 4 consecutive output columns of row m; returns this thread's contribution to the gate partial
 template <int EPI>
 __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m, int64_t n, float (&v)[4]) {
@@ -107,12 +142,7 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
         }
         case OTTER_EPI_GELU: {
             if (g.C2) store4(g.C2, m * g.ldc2 + n, g.cdt, v);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float cdf, pdf;
-                gelu_cdf_pdf(v[i], cdf, pdf);
-                o[i] = v[i] * cdf;
-            }
+            gelu_apply<4>(g.cdt == OTTER_BF16, v, o);   // bf16 results: the packed polynomial, as in the full-tile tails (tail_apply)
             store4(g.C, m * g.ldc + n, g.cdt, o);
             break;
         }
@@ -135,14 +165,7 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
                     o[i] = s * v[i] * (2.0f * r);
                 }
             } else if (g.aux_gelu) {   // tested outside the element loop (a per-element scalar branch serialises the chains)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // gelu and gelu' share the erf: one transcendental chain instead of two
-                    float cdf, pdf;
-                    gelu_cdf_pdf(a[i], cdf, pdf);
-                    part += v[i] * (a[i] * cdf);
-                    o[i] = s * v[i] * (cdf + a[i] * pdf);
-                }
+                part += gelu_bwd_apply<4>(g.cdt == OTTER_BF16, s, v, a, o);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -200,12 +223,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m
         }
         case OTTER_EPI_GELU: {
             if (g.C2) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float cdf, pdf;
-                gelu_cdf_pdf(v[i], cdf, pdf);
-                o[i] = v[i] * cdf;
-            }
+            gelu_apply<8>(g.cdt == OTTER_BF16, v, o);   // bf16 results: the packed polynomial, as in the full-tile tails (tail_apply)
             break;
         }
         case OTTER_EPI_SCALE_RES: {
@@ -226,13 +244,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m
                     o[i] = s * v[i] * (2.0f * r);
                 }
             } else if (g.aux_gelu) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float cdf, pdf;
-                    gelu_cdf_pdf(a[i], cdf, pdf);
-                    part += v[i] * (a[i] * cdf);
-                    o[i] = s * v[i] * (cdf + a[i] * pdf);
-                }
+                part += gelu_bwd_apply<8>(g.cdt == OTTER_BF16, s, v, a, o);
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -394,12 +406,7 @@ __device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t 
             if constexpr (NE == 8) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
             else store4(g.C2, m * g.ldc2 + n, g.cdt, v);
         }
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            float cdf, pdf;
-            gelu_cdf_pdf(v[i], cdf, pdf);
-            o[i] = v[i] * cdf;
-        }
+        gelu_apply<NE>(g.cdt == OTTER_BF16, v, o);   // (the dtype is a compile-time constant in the full-tile tails)
     } else if constexpr (EPI == OTTER_EPI_SCALE_RES) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) o[i] = v[i] * s + a[i];
@@ -414,13 +421,7 @@ __device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t 
                 o[i] = s * v[i] * (2.0f * r);
             }
         } else if (g.aux_gelu) {
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                float cdf, pdf;
-                gelu_cdf_pdf(a[i], cdf, pdf);
-                part += v[i] * (a[i] * cdf);
-                o[i] = s * v[i] * (cdf + a[i] * pdf);
-            }
+            part += gelu_bwd_apply<NE>(g.cdt == OTTER_BF16, s, v, a, o);
         } else {
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
@@ -596,6 +597,118 @@ __device__ __forceinline__ float tail_wave_full(const GemmArgs& g, float s, cons
     } else {                                       // residual / aux kinds always read their input
         if (idt == OTTER_BF16) return tail_wave_full_t<EPI, CBF16, true, NS, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
         return tail_wave_full_t<EPI, CBF16, false, NS, true>(g, s, acc, blk4, m_wave, n_wave, lane, ip, ild);
+    }
+}
+
+// ---- tail of the cross-tile form (round 6): ONE 8 KB parking stripe per wave, above the ring ----
+// The ring (2 x 64 KB) is busy during this tail -- the next tile's first two K-tiles are landing in it -- so a wave parks in the 32 KB of LDS
+// above it: one stripe of 32 rows x 64 fp32 = 8192 B per wave, unpadded (256-byte rows = one full sweep of the 64 banks), 16-byte chunk c
+// of row r stored at chunk c ^ (r & 15): the eight lanes of a ds_write_b128 group (8 rows, one chunk) and the sixteen of a ds_read_b128 group hit
+// distinct bank quads.  Single-buffered: stripe s + 1 is parked right behind the read-back of stripe s (a wave's LDS operations execute in order,
+// so the reads see the old stripe) and lands under the arithmetic and the global accesses of stripe s.
+constexpr int XPARK_BYTES = 32 * 256;   // per wave
+__device__ __forceinline__ void xpark_stripe(unsigned base /* LDS byte address of the wave's stripe */, int st, int lane) {
+    const unsigned r = (unsigned)lane & 15u, gq = (unsigned)lane >> 4;
+    const unsigned row = base + r * 256u;
+    const unsigned a0 = row + (((0u + gq) ^ r) << 4), a1 = row + (((4u + gq) ^ r) << 4), a2 = row + (((8u + gq) ^ r) << 4), a3 = row + (((12u + gq) ^ r) << 4);
+#define XPARK_BLOCK(ADDR_, A_, MI_, NI_)                                                                                               \
+    asm volatile("ds_write_b128 %0, a[%c1:%c2] offset:%c3" : : "v"(ADDR_), "n"(((MI_) * 8 + (NI_)) * 4), "n"(((MI_) * 8 + (NI_)) * 4 + 3), \
+                 "n"((A_) * 4096) : "memory")
+#define XPARK_STRIPE(ST_)                                                                                                              \
+    do {                                                                                                                              \
+        XPARK_BLOCK(a0, 0, 2 * ((ST_) >> 1), 4 * ((ST_) & 1)); XPARK_BLOCK(a1, 0, 2 * ((ST_) >> 1), 4 * ((ST_) & 1) + 1);                \
+        XPARK_BLOCK(a2, 0, 2 * ((ST_) >> 1), 4 * ((ST_) & 1) + 2); XPARK_BLOCK(a3, 0, 2 * ((ST_) >> 1), 4 * ((ST_) & 1) + 3);            \
+        XPARK_BLOCK(a0, 1, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1)); XPARK_BLOCK(a1, 1, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1) + 1);        \
+        XPARK_BLOCK(a2, 1, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1) + 2); XPARK_BLOCK(a3, 1, 2 * ((ST_) >> 1) + 1, 4 * ((ST_) & 1) + 3);    \
+    } while (0)
+    switch (st) {   // run-time stripe index (a scalar branch tree): the AGPR block numbers are immediates
+        case 0: XPARK_STRIPE(0); break;
+        case 1: XPARK_STRIPE(1); break;
+        case 2: XPARK_STRIPE(2); break;
+        case 3: XPARK_STRIPE(3); break;
+        case 4: XPARK_STRIPE(4); break;
+        case 5: XPARK_STRIPE(5); break;
+        case 6: XPARK_STRIPE(6); break;
+        default: XPARK_STRIPE(7); break;
+    }
+#undef XPARK_STRIPE
+#undef XPARK_BLOCK
+}
+// read the parked stripe back row-major (the lane -> (row, columns) map of TailShape), through the chunk swizzle
+template <bool CBF16>
+__device__ __forceinline__ void xpark_read(const char* __restrict__ stripe, int lane, float (&v)[TailShape<CBF16>::NIT][TailShape<CBF16>::NE]) {
+    using T = TailShape<CBF16>;
+#pragma unroll
+    for (int it = 0; it < T::NIT; ++it) {
+        const int row = T::row(lane, it), c0 = T::col(lane) >> 2;
+        const char* src = stripe + row * 256 + ((c0 ^ (row & 15)) << 4);
+        const float4 t0 = *reinterpret_cast<const float4*>(src);
+        v[it][0] = t0.x; v[it][1] = t0.y; v[it][2] = t0.z; v[it][3] = t0.w;
+        if constexpr (CBF16) {   // c0 is even: chunk c0 + 1 lies at the address with bit 4 flipped
+            const float4 t1 = *reinterpret_cast<const float4*>(stripe + row * 256 + (((c0 ^ (row & 15)) << 4) ^ 16));
+            v[it][4] = t1.x; v[it][5] = t1.y; v[it][6] = t1.z; v[it][7] = t1.w;
+        }
+    }
+}
+template <int EPI, bool CBF16, bool INBF16>
+__device__ __forceinline__ float xtail_stripe_apply(GemmArgs g, float s, const float (&v)[TailShape<CBF16>::NIT][TailShape<CBF16>::NE], int64_t m_base,
+                                                    int64_t n_base, int lane, const uint4 (&raw)[TailShape<CBF16>::NIT][2], bool has_in) {
+    using T = TailShape<CBF16>;
+    float part = 0.f;
+    g.cdt = CBF16 ? OTTER_BF16 : OTTER_F32;
+#pragma unroll
+    for (int it = 0; it < T::NIT; ++it) {
+        float a[T::NE];
+        if (has_in) cvt_raw<T::NE, INBF16>(raw[it], a);
+        else {
+#pragma unroll
+            for (int i = 0; i < T::NE; ++i) a[i] = 0.f;
+        }
+        part += tail_apply<EPI, T::NE>(g, s, m_base + T::row(lane, it), n_base + T::col(lane), v[it], a, has_in);
+    }
+    return part;
+}
+template <int EPI, bool CBF16, bool INBF16, bool HASIN>
+__device__ __forceinline__ float xtail_wave_full_t(const GemmArgs& g, float s, char* __restrict__ stripe, int64_t m_wave, int64_t n_wave, int lane,
+                                                   const void* ip, int64_t ild) {
+    using T = TailShape<CBF16>;
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stripe;
+    float part = 0.f;
+    uint4 bufA[T::NIT][2], bufB[T::NIT][2];   // input stripes, requested two stripes ahead of their use (see tail_wave_full_t)
+    if (HASIN) {
+        tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave, lane, bufA);
+        tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave, n_wave + 64, lane, bufB);
+    }
+    xpark_stripe(base, 0, lane);
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {   // stripes 2 q (bufA) and 2 q + 1 (bufB)
+        float v[T::NIT][T::NE];
+        __builtin_amdgcn_wave_barrier();
+        xpark_read<CBF16>(stripe, lane, v);
+        xpark_stripe(base, 2 * q + 1, lane);
+        part += xtail_stripe_apply<EPI, CBF16, INBF16>(g, s, v, m_wave + q * 32, n_wave, lane, bufA, HASIN);
+        if (HASIN && q < 3) tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + (q + 1) * 32, n_wave, lane, bufA);
+        __builtin_amdgcn_wave_barrier();
+        xpark_read<CBF16>(stripe, lane, v);
+        if (q < 3) xpark_stripe(base, 2 * q + 2, lane);
+        part += xtail_stripe_apply<EPI, CBF16, INBF16>(g, s, v, m_wave + q * 32, n_wave + 64, lane, bufB, HASIN);
+        if (HASIN && q < 3) tail_stripe_load<EPI, CBF16, INBF16>(ip, ild, m_wave + (q + 1) * 32, n_wave + 64, lane, bufB);
+    }
+    return part;
+}
+template <int EPI, bool CBF16>
+__device__ __forceinline__ float xtail_wave_full(const GemmArgs& g, float s, char* __restrict__ stripe, int64_t m_wave, int64_t n_wave, int lane) {
+    const void* ip; int64_t ild; int idt;
+    const bool has_in = tail_input<EPI>(g, ip, ild, idt);
+    if constexpr (EPI == OTTER_EPI_GELU) {
+        return xtail_wave_full_t<EPI, CBF16, true, false>(g, s, stripe, m_wave, n_wave, lane, ip, ild);
+    } else if constexpr (EPI == OTTER_EPI_STORE) {
+        if (!has_in) return xtail_wave_full_t<EPI, CBF16, true, false>(g, s, stripe, m_wave, n_wave, lane, ip, ild);
+        if (idt == OTTER_BF16) return xtail_wave_full_t<EPI, CBF16, true, true>(g, s, stripe, m_wave, n_wave, lane, ip, ild);
+        return xtail_wave_full_t<EPI, CBF16, false, true>(g, s, stripe, m_wave, n_wave, lane, ip, ild);
+    } else {
+        if (idt == OTTER_BF16) return xtail_wave_full_t<EPI, CBF16, true, true>(g, s, stripe, m_wave, n_wave, lane, ip, ild);
+        return xtail_wave_full_t<EPI, CBF16, false, true>(g, s, stripe, m_wave, n_wave, lane, ip, ild);
     }
 }
 
@@ -1440,7 +1553,8 @@ __device__ __forceinline__ bf16x8_t ldf_tr_rt(unsigned lane_const, int koff, int
 #ifndef OTTER_KMDBG
 #define OTTER_KMDBG 0   // debug builds only (python -m otter_amd.build --define OTTER_KMDBG=n sfx): 1 = builtin MFMA, 2 = builtin LDS-DMA
 #endif
-template <int EPI, int SCH, bool TA = false, bool TB = false>
+// XT (round 6, variant 31): the DMA ring keeps running ACROSS the tiles of a persistent workgroup -- see the block comment at T4_XT_* below.
+template <int EPI, int SCH, bool TA = false, bool TB = false, bool XT = false>
 __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, NT = 256;
     constexpr int TILE = (BM + BN) * 128;  // 64 KB: [256 A rows ; 256 B rows] x 128 B  (K-major operand: [64 k][256 m] x 2 B, same 32 KB)
@@ -1533,9 +1647,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 
     const int ntiles = g.gm * g.gn;
     uint32_t oa[8], ob[8];
+    // XT: scalar byte offsets (tile base + K position) of the K-tile the NEXT dma() calls fetch, set by xt_setk(); the per-lane offsets
+    // oa / ob are then tile-invariant (rows past M / N lie outside the descriptor and read as zeros: no clamp)
+    uint32_t sa_k = 0, sb_k = 0;
     // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
+    // plain form: K-tiles walked from `krot_plain` on (g.korder bits 0-1, a function of the tile's index: see xt_tile) -- kt is the logical index
+    int krot_plain = 0;
     auto dma = [&](int bufv, int kt, int p) {
         const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
+        if constexpr (!XT) {
+            kt += krot_plain;
+            if (kt >= nk) kt -= nk;
+        }
+        if constexpr (XT) {   // asm issue for every instantiation: invisible to hipcc's wait-count pass, counted by the schedule's own s_waitcnt
+            const unsigned dst = smem_lds + (unsigned)wbase;
+            if (p < 8) gemm_dma16_asm(rs4_a, dst, oa[TA ? (p & 1) : (p & 7)], TA ? sa_k + (uint32_t)((p & 7) >> 1) * ksa : sa_k);
+            else gemm_dma16_asm(rs4_b, dst, ob[TB ? (p & 1) : (p & 7)], TB ? sb_k + (uint32_t)((p & 7) >> 1) * ksb : sb_k);
+            return;
+        }
         // K-major operand: piece i = k-rows 8 i + (tid >> 5); pieces i and i + 2 differ by 16 rows = a UNIFORM byte offset, and the
         // swizzle of a row depends on i only through its parity -- two per-lane offsets (even / odd pieces) instead of eight, the rest
         // rides in the scalar offset (the register file of this kernel is full: 256 accumulators + 128 fragment registers)
@@ -1556,13 +1685,97 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
                                                      (int)((TB ? (uint32_t)(4 * kt + ((p & 7) >> 1)) : (uint32_t)kt) * ksb), 0, 0);
         }
     };
+    // ---- T4_XT_* : the cross-tile form (XT, round 6) --------------------------------------------------------------------------------
+    // Variant 26 pays, per output tile, a prologue (two K-tiles requested from a standing start: 5-7 k cycles on cold operands) and the
+    // drain of the tail's stores (the `__syncthreads()` that frees the parking buffers waits for vmcnt(0): loads AND stores) -- four times per
+    // launch and CU at the FFN shapes, which is the whole distance to hipBLASLt's kernel of the same tile and pipeline there (its
+    // workgroups end behind their last store and the next one's prologue runs beside the drain).  Here the ring simply keeps running:
+    //   * the K-tile after a tile's last one is the NEXT tile's first: K-tile 0 of tile i+1 is requested in iteration nk-2 of tile i
+    //     (into buffer 0, exactly where the steady state would put K-tile nk), K-tile 1 right behind tile i's tail (into buffer 1);
+    //   * the tail parks its stripes in buffer 1 + the spare LDS above the ring (two stripes per wave instead of four) and is never
+    //     waited for: its stores retire under the next tile's first K-tiles (iteration 0's `vmcnt(14)` is the first wait that counts them);
+    //   * per-lane DMA offsets are tile-invariant (the tile's base rides in the scalar offset), so a tile switch is a few SALU ops;
+    //   * every DMA is issued from asm (as in the K-major instantiations): hipcc's wait-count pass never sees an LDS-DMA in flight and
+    //     puts no vmcnt(0) in front of the tail's LDS traffic; completion is counted by hand (vmcnt + raw s_barrier).
+    // K order (g.korder, diagnostics + A/B): tile (m, n) may walk its K-tiles rotated by `krot` and permuted inside aligned groups
+    // (kgm + 1 K-tiles, offset kc), see xt_tile(): workgroups that share an operand panel then request DIFFERENT K-tiles at the same
+    // instant, so that a panel's first touch (an HBM miss) is paid by one of its sharers per K-tile instead of by all of them at once.
+    struct XtTile { uint32_t tba, tbb; int krot, kgm, kc; int64_t m0, n0; };
+    auto xt_tile = [&](int vbx) {
+        XtTile r;
+        int tm, tn;
+        tile_of_block(g, vbx, tm, tn);
+        r.m0 = (int64_t)tm * BM; r.n0 = (int64_t)tn * BN;
+        r.tba = TA ? (uint32_t)r.m0 * 2u : (uint32_t)r.m0 * (uint32_t)g.lda * 2u;
+        r.tbb = TB ? (uint32_t)r.n0 * 2u : (uint32_t)r.n0 * (uint32_t)g.ldb * 2u;
+        // (xcd: the XCD the tile runs on when the grid is a multiple of 8 workgroups -- always, but for odd CU budgets; taken from the TILE's
+        //  index so that the K order, hence the fp32 summation order, does not depend on the grid mode)
+        const int rotm = g.korder & 3, perm = (g.korder >> 2) & 3, xcd = vbx & 7;
+        int rot = 0;
+        if (rotm == 1) rot = (int)((0x13023120u >> (4 * xcd)) & 3u) * (nk >> 2);   // XCDs that share an A / B panel: halves / quarters apart
+        else if (rotm == 2) rot = (xcd * nk) >> 3;
+        else if (rotm == 3) rot = ((tn >> 2) & 3) * (nk >> 2);   // by the tile's N panel (4 tiles wide) only: rows of C do not influence their own K order
+        int gmk = perm == 1 ? 3 : (perm == 2 ? 7 : (perm == 3 ? 1 : 0));
+        if (nk & gmk) gmk = 0;
+        r.krot = __builtin_amdgcn_readfirstlane(rot);
+        r.kgm = __builtin_amdgcn_readfirstlane(gmk);
+        r.kc = __builtin_amdgcn_readfirstlane((perm == 3 ? (tm + tn) : (tm + 2 * tn)) & gmk);
+        return r;
+    };
+    // scalar offsets of logical K-tile kt of tile T for the dma() calls that follow
+    auto xt_setk = [&](const XtTile& T, int kt) {
+        int x = kt + T.krot;
+        if (x >= nk) x -= nk;
+        const int kp = (x & ~T.kgm) | ((x + T.kc) & T.kgm);
+        sa_k = __builtin_amdgcn_readfirstlane(T.tba + (uint32_t)kp * (TA ? 4u * ksa : ksa));
+        sb_k = __builtin_amdgcn_readfirstlane(T.tbb + (uint32_t)kp * (TB ? 4u * ksb : ksb));
+    };
+    constexpr int XT_PARK = 2 * TILE;       // the wave's parking stripe: XPARK_BYTES each, above the ring (the whole 160 KB of LDS are in use)
+    XtTile xt_cur = {}, xt_nxt = {};
+    bool xt_have = false;                   // K-tiles 0 and 1 of the tile about to start were requested by the previous tile's K loop
+    int xt_slack = 0;                       // tail operations of the previous tile that iteration 0's wait for K-tile 1 may leave in flight
+    if constexpr (XT) {
+        // start phase (g.korder bits 4-6 = d, diagnostics + A/B): workgroup b waits ((b >> 3) & 3) * d * 1024 cycles before its first tile.  All
+        // workgroups of a launch run tiles of equal length, so without it every CU reaches its tail in the same microseconds and the chip's
+        // whole output of that round (256 x 128-256 KB) hits the fabric at once: the tails are write-bandwidth bound (bf16 store 10 k cycles,
+        // GELU with its two outputs 27 k, profiles/r06_xt_timeline*.txt), while the K loops in between leave the write path idle
+        {
+            const int dph = (g.korder >> 4) & 7, ph = (int)((blockIdx.x >> 3) & 3);
+            for (int i = 0; i < dph * ph; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+            const int slot = phys ^ ((row >> 1) & 7);
+            const int krow = c >> 5, c16 = c & 31;
+            const int mlog = ((((c16 >> 1) ^ ((krow & 3) | (((krow >> 3) & 1) << 2))) << 1) | (c16 & 1)) * 8;
+            if constexpr (TA) { if (i < 2) oa[i] = ((uint32_t)krow * (uint32_t)g.lda + (uint32_t)mlog) * 2u; }
+            else oa[i] = ((uint32_t)row * (uint32_t)g.lda + (uint32_t)(slot * 8)) * 2u;
+            if constexpr (TB) { if (i < 2) ob[i] = ((uint32_t)krow * (uint32_t)g.ldb + (uint32_t)mlog) * 2u; }
+            else ob[i] = ((uint32_t)row * (uint32_t)g.ldb + (uint32_t)(slot * 8)) * 2u;
+        }
+    }
     for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
         int tile_m, tile_n;
         tile_of_block(g, vb, tile_m, tile_n);
         const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
         TMARK(0);
+        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (g.cdt == OTTER_F32 || g.wide);
+        // XT: this tile's K loop requests the next tile's first two K-tiles when there is one and when its own tail leaves the ring alone
+        // (the full-tile tail parks above the ring; the masked tail of an edge tile uses the ring's LDS, as in variant 26)
+        bool xt_pre = false;
+        if constexpr (!XT) {
+            const int rotm = g.korder & 3, xcd = vb & 7;
+            krot_plain = __builtin_amdgcn_readfirstlane(rotm == 1 ? (int)((0x13023120u >> (4 * xcd)) & 3u) * (nk >> 2)
+                                                        : (rotm == 2 ? (xcd * nk) >> 3 : (rotm == 3 ? ((tile_n >> 2) & 3) * (nk >> 2) : 0)));
+        }
+        if constexpr (XT) {
+            xt_cur = xt_tile(vb);
+            xt_pre = full && (vb + (int)gridDim.x < ntiles);
+            xt_nxt = xt_pre ? xt_tile(vb + (int)gridDim.x) : xt_cur;
+        }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8 && !XT; ++i) {
             const int c = i * NT + tid, row = c >> 3, phys = c & 7;
             const int slot = phys ^ ((row >> 1) & 7);
             int64_t ga = m0 + row; if (ga > g.M - 1) ga = g.M - 1;
@@ -1578,13 +1791,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             else ob[i] = (uint32_t)((gb * g.ldb + slot * 8) * 2);
         }
         // ---- prologue: K-tiles 0 and 1 in flight, 0 readable; the 256 accumulator registers are zeroed while they land ----
+        if constexpr (XT) {
+            if (!xt_have) {   // first tile of the workgroup, or behind an edge tile: a standing start, as in variant 26
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // (an edge tile's masked tail has read its parking buffers out of the ring)
+                xt_setk(xt_cur, 0);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) dma(0, 0, p);
+                for (int p = 0; p < 16; ++p) dma(0, 0, p);
+                xt_setk(xt_cur, 1);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) dma(1, 1, p);
+                for (int p = 0; p < 16; ++p) dma(1, 1, p);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
+            // K-tile 0 is in buffer 0 as far as this wave's pieces go (waited for above, or behind the previous K loop): the barrier makes it so
+            // across waves.  K-tile 1 is in flight, and so may be the previous tile's stores (xt_slack)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) dma(0, 0, p);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) dma(1, 1, p);
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x4_t acc[8][8];
-        constexpr bool XACC = (TA || TB) && !(OTTER_KMDBG & 1);   // accumulators in explicit AGPRs (asm MFMAs)
+        // accumulators in explicit AGPRs (asm MFMAs): the K-major instantiations and EVERY cross-tile instantiation (with the builtin MFMA
+        // hipcc re-homes accumulator blocks around the restructured tile loop: hundreds of v_accvgpr_mov at the K loop's entry, spills)
+        constexpr bool XACC = (TA || TB || XT) && !(OTTER_KMDBG & 1);
         if constexpr (XACC) {
             ACC_ZERO_ROW(0); ACC_ZERO_ROW(1); ACC_ZERO_ROW(2); ACC_ZERO_ROW(3); ACC_ZERO_ROW(4); ACC_ZERO_ROW(5); ACC_ZERO_ROW(6); ACC_ZERO_ROW(7);
         } else {
@@ -1596,8 +1829,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
                     for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!XT) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         asm volatile("" ::: "memory");
         bf16x8_t fm[2][8], fn[2][8];  // [k-step][16-row block]: fm = A rows (b-operand), fn = B rows (a-operand)
 #pragma unroll
@@ -1619,270 +1854,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
                          : : "v"(fn[KS][NI]), "v"(fm[KS][MI]), "n"(((MI) * 8 + (NI)) * 4), "n"(((MI) * 8 + (NI)) * 4 + 3) : AC_##MI##_##NI); \
         else acc[MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0);                  \
     } while (0)
-// ---- GENERATED by tools/gen/gemm_t4_schedule.py (do not edit by hand) ----
-#define KTILE_T0(BUF, TV, DMA, NEXT)                                                                                                                                                            \
-    do {                                                                                                                                                                                        \
-        MMA(0, 0, 0); SB(); LDF(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 1, 0); SB();                                                                                                                                                                     \
-        MMA(0, 0, 1); SB(); LDF(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                          \
-        MMA(0, 1, 1); SB();                                                                                                                                                                     \
-        MMA(0, 2, 0); SB(); LDF(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 2, 1); SB();                                                                                                                                                                     \
-        MMA(0, 0, 2); SB(); LDF(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                          \
-        MMA(0, 1, 2); SB();                                                                                                                                                                     \
-        MMA(0, 2, 2); SB(); LDF(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 3, 0); SB();                                                                                                                                                                     \
-        MMA(0, 3, 1); SB(); LDF(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                          \
-        MMA(0, 3, 2); SB();                                                                                                                                                                     \
-        MMA(0, 0, 3); SB(); LDF(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 1, 3); SB();                                                                                                                                                                     \
-        MMA(0, 2, 3); SB(); LDF(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                          \
-        MMA(0, 3, 3); SB();                                                                                                                                                                     \
-        MMA(0, 4, 0); SB(); LDF(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                          \
-        MMA(0, 4, 1); SB();                                                                                                                                                                     \
-        MMA(0, 4, 2); SB(); LDF(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                          \
-        MMA(0, 4, 3); SB();                                                                                                                                                                     \
-        MMA(0, 0, 4); SB(); LDF(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                          \
-        MMA(0, 1, 4); SB();                                                                                                                                                                     \
-        MMA(0, 2, 4); SB(); LDF(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                          \
-        MMA(0, 3, 4); SB();                                                                                                                                                                     \
-        MMA(0, 4, 4); SB(); LDF(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                          \
-        MMA(0, 5, 0); SB();                                                                                                                                                                     \
-        MMA(0, 5, 1); SB(); LDF(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                          \
-        MMA(0, 5, 2); SB();                                                                                                                                                                     \
-        MMA(0, 5, 3); SB(); LDF(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                          \
-        MMA(0, 5, 4); SB();                                                                                                                                                                     \
-        MMA(0, 0, 5); SB(); LDF(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                          \
-        MMA(0, 1, 5); SB();                                                                                                                                                                     \
-        MMA(0, 2, 5); SB();                                                                                                                                                                     \
-        MMA(0, 3, 5); SB();                                                                                                                                                                     \
-        MMA(0, 4, 5); SB();                                                                                                                                                                     \
-        MMA(0, 5, 5); SB();                                                                                                                                                                     \
-        MMA(0, 6, 0); SB();                                                                                                                                                                     \
-        MMA(0, 6, 1); SB();                                                                                                                                                                     \
-        MMA(0, 6, 2); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
-        MMA(0, 6, 3); SB();                                                                                                                                                                     \
-        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
-        MMA(0, 6, 5); SB();                                                                                                                                                                     \
-        MMA(0, 0, 6); SB();                                                                                                                                                                     \
-        MMA(0, 1, 6); SB();                                                                                                                                                                     \
-        MMA(0, 2, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
-        MMA(0, 3, 6); SB();                                                                                                                                                                     \
-        MMA(0, 4, 6); SB();                                                                                                                                                                     \
-        MMA(0, 5, 6); SB();                                                                                                                                                                     \
-        MMA(0, 6, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
-        MMA(0, 7, 0); SB();                                                                                                                                                                     \
-        MMA(0, 7, 1); SB();                                                                                                                                                                     \
-        MMA(0, 7, 2); SB();                                                                                                                                                                     \
-        MMA(0, 7, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
-        MMA(0, 7, 4); SB();                                                                                                                                                                     \
-        MMA(0, 7, 5); SB();                                                                                                                                                                     \
-        MMA(0, 7, 6); SB();                                                                                                                                                                     \
-        MMA(0, 0, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
-        MMA(0, 1, 7); SB();                                                                                                                                                                     \
-        MMA(0, 2, 7); SB();                                                                                                                                                                     \
-        MMA(0, 3, 7); SB();                                                                                                                                                                     \
-        MMA(0, 4, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
-        MMA(0, 5, 7); SB();                                                                                                                                                                     \
-        MMA(0, 6, 7); SB();                                                                                                                                                                     \
-        MMA(0, 7, 7); SB();                                                                                                                                                                     \
-        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
-        MMA(1, 1, 0); SB();                                                                                                                                                                     \
-        MMA(1, 0, 1); SB();                                                                                                                                                                     \
-        MMA(1, 1, 1); SB();                                                                                                                                                                     \
-        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
-        MMA(1, 2, 1); SB();                                                                                                                                                                     \
-        MMA(1, 0, 2); SB();                                                                                                                                                                     \
-        MMA(1, 1, 2); SB();                                                                                                                                                                     \
-        MMA(1, 2, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
-        MMA(1, 3, 0); SB();                                                                                                                                                                     \
-        MMA(1, 3, 1); SB();                                                                                                                                                                     \
-        MMA(1, 3, 2); SB();                                                                                                                                                                     \
-        MMA(1, 0, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
-        MMA(1, 1, 3); SB();                                                                                                                                                                     \
-        MMA(1, 2, 3); SB();                                                                                                                                                                     \
-        MMA(1, 3, 3); SB();                                                                                                                                                                     \
-        MMA(1, 4, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
-        MMA(1, 4, 1); SB();                                                                                                                                                                     \
-        MMA(1, 4, 2); SB();                                                                                                                                                                     \
-        MMA(1, 4, 3); SB();                                                                                                                                                                     \
-        MMA(1, 0, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
-        MMA(1, 1, 4); SB();                                                                                                                                                                     \
-        MMA(1, 2, 4); SB();                                                                                                                                                                     \
-        MMA(1, 3, 4); SB();                                                                                                                                                                     \
-        MMA(1, 4, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
-        MMA(1, 5, 0); SB();                                                                                                                                                                     \
-        MMA(1, 5, 1); SB();                                                                                                                                                                     \
-        MMA(1, 5, 2); SB();                                                                                                                                                                     \
-        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
-        MMA(1, 5, 4); SB();                                                                                                                                                                     \
-        MMA(1, 0, 5); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
-        MMA(1, 1, 5); SB();                                                                                                                                                                     \
-        MMA(1, 2, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
-        MMA(1, 3, 5); SB(); if (NEXT) { LDF(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
-        MMA(1, 4, 5); SB();                                                                                                                                                                     \
-        MMA(1, 5, 5); SB(); if (NEXT) { LDF(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                      \
-        MMA(1, 6, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
-        MMA(1, 6, 1); SB(); if (NEXT) { LDF(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
-        MMA(1, 6, 2); SB();                                                                                                                                                                     \
-        MMA(1, 6, 3); SB(); if (NEXT) { LDF(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                      \
-        MMA(1, 6, 4); SB();                                                                                                                                                                     \
-        MMA(1, 6, 5); SB(); if (NEXT) { LDF(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
-        MMA(1, 0, 6); SB();                                                                                                                                                                     \
-        MMA(1, 1, 6); SB(); if (NEXT) { LDF(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                      \
-        MMA(1, 2, 6); SB();                                                                                                                                                                     \
-        MMA(1, 3, 6); SB(); if (NEXT) { LDF(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
-        MMA(1, 4, 6); SB();                                                                                                                                                                     \
-        MMA(1, 5, 6); SB(); if (NEXT) { LDF(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                      \
-        MMA(1, 6, 6); SB();                                                                                                                                                                     \
-        MMA(1, 7, 0); SB(); if (NEXT) { LDF(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
-        MMA(1, 7, 1); SB();                                                                                                                                                                     \
-        MMA(1, 7, 2); SB(); if (NEXT) { LDF(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                      \
-        MMA(1, 7, 3); SB();                                                                                                                                                                     \
-        MMA(1, 7, 4); SB(); if (NEXT) { LDF(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
-        MMA(1, 7, 5); SB();                                                                                                                                                                     \
-        MMA(1, 7, 6); SB(); if (NEXT) { LDF(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                      \
-        MMA(1, 0, 7); SB();                                                                                                                                                                     \
-        MMA(1, 1, 7); SB(); if (NEXT) { LDF(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
-        MMA(1, 2, 7); SB();                                                                                                                                                                     \
-        MMA(1, 3, 7); SB(); if (NEXT) { LDF(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                      \
-        MMA(1, 4, 7); SB();                                                                                                                                                                     \
-        MMA(1, 5, 7); SB(); if (NEXT) { LDF(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
-        MMA(1, 6, 7); SB();                                                                                                                                                                     \
-        MMA(1, 7, 7); SB(); if (NEXT) { LDF(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                      \
+// the wait for K-tile t + 1 in front of barrier #2: N pieces of K-tile t + 2 have been issued behind it (DMA), none (!DMA), or -- the first
+// iteration of a cross-tile tile (DMA == 2) -- N pieces plus the previous tile's tail, of which xt_slack operations may stay in flight
+#define T4_WAIT_NEXT(DMA, N)                                                                                              \
+    do {                                                                                                                  \
+        if ((DMA) == 2) {                                                                                                 \
+            if (xt_slack) asm volatile("s_waitcnt vmcnt(%c0)" : : "n"((N) + 32) : "memory");                              \
+            else asm volatile("s_waitcnt vmcnt(%c0)" : : "n"(N) : "memory");                                              \
+        } else if (DMA) asm volatile("s_waitcnt vmcnt(%c0)" : : "n"(N) : "memory");                                       \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
     } while (0)
-// K-major instantiations: split fragment reads (tools/gen/gemm_t4_schedule.py x0)
-#define KTILE_X0(BUF, TV, DMA, NEXT)                                                                                                                                                            \
-    do {                                                                                                                                                                                        \
-        MMA(0, 0, 0); SB(); LDFA(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                         \
-        MMA(0, 1, 0); SB(); LDFB(fm[1][0], ra, ra_hi, BUF, 1, 0); SB();                                                                                                                         \
-        MMA(0, 0, 1); SB(); LDFA(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                         \
-        MMA(0, 1, 1); SB(); LDFB(fn[1][0], rb, rb_hi, BUF, 1, 0); SB();                                                                                                                         \
-        MMA(0, 2, 0); SB(); LDFA(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                         \
-        MMA(0, 2, 1); SB(); LDFB(fm[1][1], ra, ra_hi, BUF, 1, 1); SB();                                                                                                                         \
-        MMA(0, 0, 2); SB(); LDFA(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                         \
-        MMA(0, 1, 2); SB(); LDFB(fn[1][1], rb, rb_hi, BUF, 1, 1); SB();                                                                                                                         \
-        MMA(0, 2, 2); SB(); LDFA(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                         \
-        MMA(0, 3, 0); SB(); LDFB(fm[1][2], ra, ra_hi, BUF, 1, 2); SB();                                                                                                                         \
-        MMA(0, 3, 1); SB(); LDFA(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                         \
-        MMA(0, 3, 2); SB(); LDFB(fn[1][2], rb, rb_hi, BUF, 1, 2); SB();                                                                                                                         \
-        MMA(0, 0, 3); SB(); LDFA(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                         \
-        MMA(0, 1, 3); SB(); LDFB(fm[1][3], ra, ra_hi, BUF, 1, 3); SB();                                                                                                                         \
-        MMA(0, 2, 3); SB(); LDFA(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                         \
-        MMA(0, 3, 3); SB(); LDFB(fn[1][3], rb, rb_hi, BUF, 1, 3); SB();                                                                                                                         \
-        MMA(0, 4, 0); SB(); LDFA(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                         \
-        MMA(0, 4, 1); SB(); LDFB(fm[1][4], ra, ra_hi, BUF, 1, 4); SB();                                                                                                                         \
-        MMA(0, 4, 2); SB(); LDFA(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                         \
-        MMA(0, 4, 3); SB(); LDFB(fn[1][4], rb, rb_hi, BUF, 1, 4); SB();                                                                                                                         \
-        MMA(0, 0, 4); SB(); LDFA(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                         \
-        MMA(0, 1, 4); SB(); LDFB(fm[1][5], ra, ra_hi, BUF, 1, 5); SB();                                                                                                                         \
-        MMA(0, 2, 4); SB(); LDFA(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                         \
-        MMA(0, 3, 4); SB(); LDFB(fn[1][5], rb, rb_hi, BUF, 1, 5); SB();                                                                                                                         \
-        MMA(0, 4, 4); SB(); LDFA(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                         \
-        MMA(0, 5, 0); SB(); LDFB(fm[1][6], ra, ra_hi, BUF, 1, 6); SB();                                                                                                                         \
-        MMA(0, 5, 1); SB(); LDFA(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                         \
-        MMA(0, 5, 2); SB(); LDFB(fn[1][6], rb, rb_hi, BUF, 1, 6); SB();                                                                                                                         \
-        MMA(0, 5, 3); SB(); LDFA(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                         \
-        MMA(0, 5, 4); SB(); LDFB(fm[1][7], ra, ra_hi, BUF, 1, 7); SB();                                                                                                                         \
-        MMA(0, 0, 5); SB(); LDFA(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                         \
-        MMA(0, 1, 5); SB(); LDFB(fn[1][7], rb, rb_hi, BUF, 1, 7); SB();                                                                                                                         \
-        MMA(0, 2, 5); SB();                                                                                                                                                                     \
-        MMA(0, 3, 5); SB();                                                                                                                                                                     \
-        MMA(0, 4, 5); SB();                                                                                                                                                                     \
-        MMA(0, 5, 5); SB();                                                                                                                                                                     \
-        MMA(0, 6, 0); SB();                                                                                                                                                                     \
-        MMA(0, 6, 1); SB();                                                                                                                                                                     \
-        MMA(0, 6, 2); SB(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();                                                                              \
-        MMA(0, 6, 3); SB();                                                                                                                                                                     \
-        MMA(0, 6, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 0); SB();                                                                                                                               \
-        MMA(0, 6, 5); SB();                                                                                                                                                                     \
-        MMA(0, 0, 6); SB();                                                                                                                                                                     \
-        MMA(0, 1, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 1); SB();                                                                                                                               \
-        MMA(0, 2, 6); SB();                                                                                                                                                                     \
-        MMA(0, 3, 6); SB();                                                                                                                                                                     \
-        MMA(0, 4, 6); SB();                                                                                                                                                                     \
-        MMA(0, 5, 6); SB(); if (DMA) dma(BUF, (TV) + 2, 2); SB();                                                                                                                               \
-        MMA(0, 6, 6); SB();                                                                                                                                                                     \
-        MMA(0, 7, 0); SB();                                                                                                                                                                     \
-        MMA(0, 7, 1); SB(); if (DMA) dma(BUF, (TV) + 2, 3); SB();                                                                                                                               \
-        MMA(0, 7, 2); SB();                                                                                                                                                                     \
-        MMA(0, 7, 3); SB();                                                                                                                                                                     \
-        MMA(0, 7, 4); SB();                                                                                                                                                                     \
-        MMA(0, 7, 5); SB(); if (DMA) dma(BUF, (TV) + 2, 4); SB();                                                                                                                               \
-        MMA(0, 7, 6); SB();                                                                                                                                                                     \
-        MMA(0, 0, 7); SB();                                                                                                                                                                     \
-        MMA(0, 1, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 5); SB();                                                                                                                               \
-        MMA(0, 2, 7); SB();                                                                                                                                                                     \
-        MMA(0, 3, 7); SB();                                                                                                                                                                     \
-        MMA(0, 4, 7); SB();                                                                                                                                                                     \
-        MMA(0, 5, 7); SB(); if (DMA) dma(BUF, (TV) + 2, 6); SB();                                                                                                                               \
-        MMA(0, 6, 7); SB();                                                                                                                                                                     \
-        MMA(0, 7, 7); SB();                                                                                                                                                                     \
-        MMA(1, 0, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 7); SB();                                                                                                                               \
-        MMA(1, 1, 0); SB();                                                                                                                                                                     \
-        MMA(1, 0, 1); SB();                                                                                                                                                                     \
-        MMA(1, 1, 1); SB();                                                                                                                                                                     \
-        MMA(1, 2, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 8); SB();                                                                                                                               \
-        MMA(1, 2, 1); SB();                                                                                                                                                                     \
-        MMA(1, 0, 2); SB();                                                                                                                                                                     \
-        MMA(1, 1, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 9); SB();                                                                                                                               \
-        MMA(1, 2, 2); SB();                                                                                                                                                                     \
-        MMA(1, 3, 0); SB();                                                                                                                                                                     \
-        MMA(1, 3, 1); SB();                                                                                                                                                                     \
-        MMA(1, 3, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 10); SB();                                                                                                                              \
-        MMA(1, 0, 3); SB();                                                                                                                                                                     \
-        MMA(1, 1, 3); SB();                                                                                                                                                                     \
-        MMA(1, 2, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 11); SB();                                                                                                                              \
-        MMA(1, 3, 3); SB();                                                                                                                                                                     \
-        MMA(1, 4, 0); SB();                                                                                                                                                                     \
-        MMA(1, 4, 1); SB();                                                                                                                                                                     \
-        MMA(1, 4, 2); SB(); if (DMA) dma(BUF, (TV) + 2, 12); SB();                                                                                                                              \
-        MMA(1, 4, 3); SB();                                                                                                                                                                     \
-        MMA(1, 0, 4); SB();                                                                                                                                                                     \
-        MMA(1, 1, 4); SB(); if (DMA) dma(BUF, (TV) + 2, 13); SB();                                                                                                                              \
-        MMA(1, 2, 4); SB();                                                                                                                                                                     \
-        MMA(1, 3, 4); SB();                                                                                                                                                                     \
-        MMA(1, 4, 4); SB();                                                                                                                                                                     \
-        MMA(1, 5, 0); SB(); if (DMA) dma(BUF, (TV) + 2, 14); SB();                                                                                                                              \
-        MMA(1, 5, 1); SB();                                                                                                                                                                     \
-        MMA(1, 5, 2); SB();                                                                                                                                                                     \
-        MMA(1, 5, 3); SB(); if (DMA) dma(BUF, (TV) + 2, 15); SB();                                                                                                                              \
-        MMA(1, 5, 4); SB();                                                                                                                                                                     \
-        MMA(1, 0, 5); SB(); if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } SB();  \
-        MMA(1, 1, 5); SB();                                                                                                                                                                     \
-        MMA(1, 2, 5); SB(); if (NEXT) { LDFA(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
-        MMA(1, 3, 5); SB(); if (NEXT) { LDFB(fm[0][0], ra, ra_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
-        MMA(1, 4, 5); SB(); if (NEXT) { LDFA(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
-        MMA(1, 5, 5); SB(); if (NEXT) { LDFB(fn[0][0], rb, rb_hi, (BUF) ^ 1, 0, 0); } SB();                                                                                                     \
-        MMA(1, 6, 0); SB(); if (NEXT) { LDFA(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
-        MMA(1, 6, 1); SB(); if (NEXT) { LDFB(fm[0][1], ra, ra_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
-        MMA(1, 6, 2); SB(); if (NEXT) { LDFA(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
-        MMA(1, 6, 3); SB(); if (NEXT) { LDFB(fn[0][1], rb, rb_hi, (BUF) ^ 1, 0, 1); } SB();                                                                                                     \
-        MMA(1, 6, 4); SB(); if (NEXT) { LDFA(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
-        MMA(1, 6, 5); SB(); if (NEXT) { LDFB(fm[0][2], ra, ra_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
-        MMA(1, 0, 6); SB(); if (NEXT) { LDFA(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
-        MMA(1, 1, 6); SB(); if (NEXT) { LDFB(fn[0][2], rb, rb_hi, (BUF) ^ 1, 0, 2); } SB();                                                                                                     \
-        MMA(1, 2, 6); SB(); if (NEXT) { LDFA(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
-        MMA(1, 3, 6); SB(); if (NEXT) { LDFB(fm[0][3], ra, ra_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
-        MMA(1, 4, 6); SB(); if (NEXT) { LDFA(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
-        MMA(1, 5, 6); SB(); if (NEXT) { LDFB(fn[0][3], rb, rb_hi, (BUF) ^ 1, 0, 3); } SB();                                                                                                     \
-        MMA(1, 6, 6); SB(); if (NEXT) { LDFA(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
-        MMA(1, 7, 0); SB(); if (NEXT) { LDFB(fm[0][4], ra, ra_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
-        MMA(1, 7, 1); SB(); if (NEXT) { LDFA(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
-        MMA(1, 7, 2); SB(); if (NEXT) { LDFB(fn[0][4], rb, rb_hi, (BUF) ^ 1, 0, 4); } SB();                                                                                                     \
-        MMA(1, 7, 3); SB(); if (NEXT) { LDFA(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
-        MMA(1, 7, 4); SB(); if (NEXT) { LDFB(fm[0][5], ra, ra_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
-        MMA(1, 7, 5); SB(); if (NEXT) { LDFA(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
-        MMA(1, 7, 6); SB(); if (NEXT) { LDFB(fn[0][5], rb, rb_hi, (BUF) ^ 1, 0, 5); } SB();                                                                                                     \
-        MMA(1, 0, 7); SB(); if (NEXT) { LDFA(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
-        MMA(1, 1, 7); SB(); if (NEXT) { LDFB(fm[0][6], ra, ra_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
-        MMA(1, 2, 7); SB(); if (NEXT) { LDFA(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
-        MMA(1, 3, 7); SB(); if (NEXT) { LDFB(fn[0][6], rb, rb_hi, (BUF) ^ 1, 0, 6); } SB();                                                                                                     \
-        MMA(1, 4, 7); SB(); if (NEXT) { LDFA(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
-        MMA(1, 5, 7); SB(); if (NEXT) { LDFB(fm[0][7], ra, ra_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
-        MMA(1, 6, 7); SB(); if (NEXT) { LDFA(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
-        MMA(1, 7, 7); SB(); if (NEXT) { LDFB(fn[0][7], rb, rb_hi, (BUF) ^ 1, 0, 7); } SB();                                                                                                     \
-    } while (0)
+// the 128-slot K-tile schedules (tools/gen/gemm_t4_schedule.py inc): KTILE_T0_0 (K-contiguous operands) / KTILE_X0_0 (K-major: split
+// transpose reads)
+#include "gemm_t4_ktile.inc"
+#define KTILE_T0 KTILE_T0_0
+#define KTILE_X0 KTILE_X0_0
 #ifdef OTTER_EXPERIMENTAL  // tools-only: variants 27-29: alternative slot placements T1-T3 of variant 26's K-tile schedule (generated by tools/gen/gemm_t4_schedule.py)
 #include "experimental/gemm_t4_placements_t1_t3.inc"
 #endif
@@ -1896,8 +1882,34 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         KT(0, t, false, true);                      \
         KT(1, t + 1, false, false);                 \
     } while (0)
+// XT: dma() fetches what xt_setk() named.  The ring runs on into the next tile: iterations nk-2 / nk-1 request ITS K-tiles 0 / 1 (xt_pre) into
+// the buffers the steady state would refill anyway.  Iteration 0 is peeled for its wait: behind a full-tile tail, K-tile 1 is followed in the
+// queue by that tail's >= 32 global accesses, which the count may leave in flight (DMA == 2, see T4_WAIT_NEXT); iteration 1's wait for
+// K-tile 2 is the first that retires them.  Needs nk >= 4 (the host falls back to the plain form below that).
+#define KLOOP_XT(KT)                                \
+    do {                                            \
+        xt_setk(xt_cur, 2);                         \
+        KT(0, 0, 2, true);                          \
+        xt_setk(xt_cur, 3);                         \
+        KT(1, 1, true, true);                       \
+        int t = 2;                                  \
+        for (; t + 2 < nk; t += 2) {                \
+            xt_setk(xt_cur, t + 2);                 \
+            KT(0, t, true, true);                   \
+            xt_setk(xt_cur, t + 3);                 \
+            KT(1, t + 1, true, true);               \
+        }                                           \
+        xt_setk(xt_nxt, 0);                         \
+        KT(0, t, xt_pre, true);                     \
+        xt_setk(xt_nxt, 1);                         \
+        KT(1, t + 1, xt_pre, false);                \
+    } while (0)
 #ifdef OTTER_EXPERIMENTAL
-        if constexpr (SCH == 0) KLOOP(KTILE_T0);
+        static_assert(!XT || SCH == 0, "the cross-tile form runs the default placement only");
+        if constexpr (XT) {
+            if constexpr (TA || TB) KLOOP_XT(KTILE_X0);
+            else KLOOP_XT(KTILE_T0);
+        } else if constexpr (SCH == 0) KLOOP(KTILE_T0);
         else if constexpr (SCH == 1) KLOOP(KTILE_T1);
         else if constexpr (SCH == 2) KLOOP(KTILE_T2);
         else KLOOP(KTILE_T3);
@@ -1906,12 +1918,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #undef KTILE_T3
 #else
         static_assert(SCH == 0, "the alternative placements of variant 26 (27-29) are in the OTTER_EXPERIMENTAL build only");
-        if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP(KTILE_X0);
+        if constexpr (XT) {
+            if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP_XT(KTILE_X0);
+            else KLOOP_XT(KTILE_T0);
+        } else if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP(KTILE_X0);
         else KLOOP(KTILE_T0);
 #endif
 #undef KLOOP
+#undef KLOOP_XT
+#undef T4_WAIT_NEXT
 #undef KTILE_X0
 #undef KTILE_T0
+#undef KTILE_T0_0
+#undef KTILE_X0_0
 #undef MMA
 
         // ---- epilogue: both buffers are dead (every fragment read retired before barrier #1 of the last K-tile, no DMA in flight) ----
@@ -1919,36 +1938,67 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         // first accumulator reads of the tail are spelled out (a 16x16x32 result is readable 8 passes + 2 after issue)
         // the tail then parks them straight out of the AGPR half (park_stripe(AgprAcc)).
         if constexpr (XACC) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        // XT: 32 pieces in flight (the next tile's K-tiles 0 and 1); K-tile 0's were requested an iteration ago -- this wave's have landed once
+        // at most the 16 of K-tile 1 are outstanding (the barrier that publishes them across waves is the one at the top of the next tile)
+        if constexpr (XT) { if (xt_pre) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
         TMARK(2);
         float part = 0.f;
-        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (g.cdt == OTTER_F32 || g.wide);
         const AgprAcc xacc;
         if (full) {
-            float* blk4 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
-            if constexpr (XACC) {
-                if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, xacc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
-                else part = tail_wave_full<EPI, false>(g, sgate, xacc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+            if constexpr (XT) {
+                // the lane index goes through an empty asm per tile: everything the tail derives from it (row numbers, 64-bit addresses, swizzled
+                // LDS offsets of every `it`) is then computed HERE and dies here -- hoisted out of the tile loop (they are loop invariant) these
+                // values stayed live across the K loop, whose file is full, and were spilled to scratch: reloads + s_waitcnt vmcnt(0) inside iteration 0
+                int lane_t = lane;
+                asm volatile("" : "+v"(lane_t));
+                char* stripe = smem + XT_PARK + wave * XPARK_BYTES;
+                if (g.cdt == OTTER_BF16) part = xtail_wave_full<EPI, true>(g, sgate, stripe, m0 + wm * 128, n0 + wn * 128, lane_t);
+                else part = xtail_wave_full<EPI, false>(g, sgate, stripe, m0 + wm * 128, n0 + wn * 128, lane_t);
             } else {
-                if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
-                else part = tail_wave_full<EPI, false>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+                float* blk4 = reinterpret_cast<float*>(smem) + wave * (TAIL_STRIPES * 32 * EPI_LD);
+                if constexpr (XACC) {
+                    if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, xacc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+                    else part = tail_wave_full<EPI, false>(g, sgate, xacc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+                } else {
+                    if (g.cdt == OTTER_BF16) part = tail_wave_full<EPI, true>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+                    else part = tail_wave_full<EPI, false>(g, sgate, acc, blk4, m0 + wm * 128, n0 + wn * 128, lane);
+                }
             }
         } else {
-            float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);
+            float* blk = reinterpret_cast<float*>(smem) + wave * (32 * EPI_LD);   // (XT: nothing was requested into the ring: xt_pre is false)
+            int lane_t = lane;
+            if constexpr (XT) asm volatile("" : "+v"(lane_t));
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                if constexpr (XACC) park_stripe(blk, xacc, st, lane);
-                else park_stripe(blk, acc, st, lane);
+                if constexpr (XACC) park_stripe(blk, xacc, st, lane_t);
+                else park_stripe(blk, acc, st, lane_t);
                 __builtin_amdgcn_wave_barrier();
-                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 128 + (st >> 1) * 32, n0 + wn * 128 + (st & 1) * 64, lane);
+                part += epilogue_stripe<EPI>(g, sgate, blk, m0 + wm * 128 + (st >> 1) * 32, n0 + wn * 128 + (st & 1) * 64, lane_t);
                 __builtin_amdgcn_wave_barrier();
             }
         }
         TMARK(3);
-        block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
-        __syncthreads();  // the next tile's prologue DMA overwrites the stripes
+        if constexpr (XT) {
+            // no drain: the stores stay in flight (iteration 1 of the next tile is the first wait that counts them).  The gate partial's
+            // cross-wave sum goes through the first word of each wave's own parking stripe (dead: its tail is over)
+            if (EPI == OTTER_EPI_GATE_BWD && g.partial != nullptr) {
+                float* red = reinterpret_cast<float*>(smem + XT_PARK);
+                part = wave_sum(part);
+                if (lane == 0) red[wave * (XPARK_BYTES / 4)] = part;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (tid == 0) g.partial[vb] = red[0] + red[XPARK_BYTES / 4] + red[2 * (XPARK_BYTES / 4)] + red[3 * (XPARK_BYTES / 4)];
+            }
+            xt_have = xt_pre;
+            xt_slack = xt_pre ? 32 : 0;
+        } else {
+            block_partial<4, EPI>(g, part, reinterpret_cast<float*>(smem), vb);
+            __syncthreads();  // the next tile's prologue DMA overwrites the stripes
+        }
         TMARK(4);
         ++tcount;
     }
+    if constexpr (XT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's look-ahead K-tile: no LDS-DMA may outlive the workgroup
 #undef LDF
 #undef LDFA
 #undef LDFB
@@ -2389,6 +2439,27 @@ int g_variant = 0;
 int g_debug = 0;
 int g_order = 0;
 int g_narrow_epilogue = 0;  // A/B hook (otter_gemm_set_debug bit 256): force the 4-wide fused tail
+// Cross-tile form of variant 26 (round 6): otter_gemm_set_debug bits 14-15 = 0 default / 1 off / 2 on, bits 16-22 = K order + start phase (GemmArgs::korder), bit 23 = use them;
+// the process default comes from OTTER_GEMM_XT / OTTER_GEMM_KORDER (read once; A/B switches of bench.py and tools/)
+int g_xt_force = 0;
+int g_korder_force = -1;
+#ifndef OTTER_T4_XT_DEFAULT
+#define OTTER_T4_XT_DEFAULT 1
+#endif
+#ifndef OTTER_T4_KORDER_DEFAULT
+#define OTTER_T4_KORDER_DEFAULT 3   // K-tiles of a tile walked from a quarter given by its N panel: -1..-4 % on cold operands (profiles/r06_xt_ab*.txt);
+                                    // mode 3 and not the XCD modes: a row of C keeps one summation order wherever it sits in the batch (DP invariant)
+#endif
+bool t4_xt_on() {
+    static int dflt = -1;
+    if (dflt < 0) { const char* e = getenv("OTTER_GEMM_XT"); dflt = e ? (e[0] != '0') : OTTER_T4_XT_DEFAULT; }
+    return g_xt_force ? g_xt_force == 2 : dflt == 1;
+}
+int t4_korder() {
+    static int dflt = -1;
+    if (dflt < 0) { const char* e = getenv("OTTER_GEMM_KORDER"); dflt = e ? (atoi(e) & 127) : OTTER_T4_KORDER_DEFAULT; }
+    return g_korder_force >= 0 ? g_korder_force : dflt;
+}
 enum Cfg { CFG_128 = 1, CFG_256 = 2, CFG_256_GLDS = 3, CFG_MS4 = 4, CFG_MS5 = 5, CFG_PH = 6, CFG_PHC = 7, CFG_WS = 8, CFG_PHB = 9, CFG_PHCB = 10, CFG_PHRB = 11, CFG_MS5B = 12, CFG_PHLB = 13, CFG_PHIB = 14, CFG_PH2B = 15, CFG_PHDB = 16, CFG_Q4 = 17, CFG_R4 = 18, CFG_R4B = 19, CFG_R4C = 20, CFG_R4P = 21, CFG_R4M = 22, CFG_R4N = 23, CFG_S4 = 25, CFG_T4 = 26, CFG_T4B = 27, CFG_T4C = 28, CFG_T4M = 29, CFG_S4H = 30, CFG_F32 = 100 };
 
 // wide: an operand spans >= 4 GB, so the kernels that address it with 32-bit byte offsets are out
@@ -2571,6 +2642,22 @@ int launch_epi(int cfg, dim3 grid, hipStream_t st, const GemmArgs& g) {
         if (!once) { int rc = set_smem(gemm_bf16_t4_kernel<EPI, 0, TA_, TB_>, smem); if (rc) return rc; once = true; }     \
         hipLaunchKernelGGL((gemm_bf16_t4_kernel<EPI, 0, TA_, TB_>), dim3(pg), dim3(256), smem, st, g);                     \
     } while (0)
+// cross-tile form: the ring (2 x 64 KB) + one 8 KB parking stripe per wave above it = all 160 KB of the CU's LDS
+#define LAUNCH_T4X(TA_, TB_)                                                                                               \
+    do {                                                                                                                   \
+        static bool once = false;                                                                                          \
+        constexpr int smem_x = 2 * 65536 + 4 * XPARK_BYTES;                                                                \
+        if (!once) { int rc = set_smem(gemm_bf16_t4_kernel<EPI, 0, TA_, TB_, true>, smem_x); if (rc) return rc; once = true; } \
+        hipLaunchKernelGGL((gemm_bf16_t4_kernel<EPI, 0, TA_, TB_, true>), dim3(pg), dim3(256), smem_x, st, g);             \
+    } while (0)
+        // (the cross-tile form peels two K-tiles at each end of a tile's K loop: >= 4 K-tiles)
+        // K-contiguous operands only: with a K-major operand the cross-tile form measured SLOWER (dW2 404 vs 396 us, profiles/r06_xt_ab*.txt):
+        // its tail is shorter, but the stores it leaves in flight hold back the in-order vmcnt waits of the next tile's first K-tiles by more
+        if (cfg == CFG_T4 && t4_xt_on() && !g.ta && !g.tb && g.K >= 256) {
+            LAUNCH_T4X(false, false);
+            return OTTER_OK;
+        }
+#undef LAUNCH_T4X
         if (g.ta || g.tb) {   // K-major operands: the backward products (dW = dy^T x: both; dx = dy W: B)
             if (g.ta && g.tb) LAUNCH_T4T(true, true);
             else if (g.tb) LAUNCH_T4T(false, true);
@@ -2685,6 +2772,8 @@ int otter_gemm_set_debug(int flags) {
     g_debug = flags & 255;  // bit 64: tile-phase timeline of variants 18-20 (otter_gemm_read_timeline)
     g_narrow_epilogue = (flags & 256) ? 1 : 0;
     g_order = (flags >> 9) & 31;  // tile-order override (bits 9-12, see tile_of_block); bit 13: non-persistent launch of variant 26
+    g_xt_force = (flags >> 14) & 3;                       // cross-tile form of variant 26: 0 default, 1 off, 2 on
+    g_korder_force = (flags & (1 << 23)) ? ((flags >> 16) & 127) : -1;   // bit 23: bits 16-22 override the K order / start phase of that form
     return OTTER_OK;
 }
 
@@ -2782,6 +2871,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
     cfg_tiles(cfg, bm, bn);
     g.dbg = g_debug;
     g.order = g_order;
+    g.korder = t4_korder();
     // (fp32 outputs stay on the 4-wide tail: there a lane's 4 columns are already a 16-byte store and 16 lanes cover a
     //  whole 256-byte row run; the 8-wide form would split every row into interleaved 16-byte halves: measured +15 %)
     g.wide = (c_dtype == OTTER_BF16 && N % 8 == 0 && ldc % 8 == 0 && (!g.C2 || g.ldc2 % 8 == 0) && (g.kind != OTTER_EPI_SCALE_RES || g.ldr % 8 == 0) &&

@@ -363,9 +363,15 @@ def test_gemm_full_tile_fast_tail(ops, variant, out_dt):
             out["accum"] = acc
         return out
 
+    from otter_amd import _capi as K_
+
     try:
+        # variant 26 walks a tile's K-tiles rotated by the tile's XCD since round 6 (another fp32 summation order than variant 13's): the
+        # bit-for-bit comparison of the TAILS runs it with the plain K order (otter_gemm_set_debug bit 23 = take bits 16-22 as the order: 0)
+        K_.check(K_.lib().otter_gemm_set_debug(1 << 23), "gemm_set_debug")
         mine, base = run(variant), run(13)
     finally:
+        K_.check(K_.lib().otter_gemm_set_debug(0), "gemm_set_debug")
         ops.set_gemm_variant(0)
     for k in base:
         if k.startswith("gpart"):   # block partials are summed in a different order (4 vs 8 waves)
@@ -389,12 +395,16 @@ def test_gemm_persistent_blocks_with_several_tiles(ops, variant):
     A = to_dev(bf16_round(r.standard_normal((M, Kd)) * 0.5), torch.bfloat16)
     B = to_dev(bf16_round(r.standard_normal((N, Kd)) * 0.5), torch.bfloat16)
     R = to_dev(r.standard_normal((M, N)).astype(np.float32))
+    from otter_amd import _capi as K_
+
     outs = {}
     try:
+        K_.check(K_.lib().otter_gemm_set_debug(1 << 23), "gemm_set_debug")   # plain K order (variant 26 rotates it by the tile's N panel: another summation order)
         for v in (13, variant):
             ops.set_gemm_variant(v)
             outs[v] = (ops.gemm_nt(A, B), ops.gemm_nt(A, B, out_dtype=torch.float32, kind=EPI_SCALE_RES, R=R))
     finally:
+        K_.check(K_.lib().otter_gemm_set_debug(0), "gemm_set_debug")
         ops.set_gemm_variant(0)
     assert torch.equal(outs[13][0], outs[variant][0]) and torch.equal(outs[13][1], outs[variant][1])
     ref = host(A[:300]).astype(np.float64) @ host(B).astype(np.float64).T

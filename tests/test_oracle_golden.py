@@ -166,3 +166,80 @@ def test_gated_xattn_at_the_benchmark_width_against_the_reference_fp32_rows():
             assert abs(s[2] - f[2]) < TOL * abs(f[2]) and np.abs(s[3:] - f[3:]).max() < TOL * np.abs(f[3:]).max(), k
     # and the reference's own bf16-autocast drift, as recorded by the generator, is what the GPU comparator test divides by: sanity
     assert 1e-3 < G.row_rel_err(gold["y_bf16"], gold["y_f32"]) < 1e-2
+
+
+# ---- oracle/torch_port.py: the torch-CPU restatement bench.py's cpu_baseline times (the reference's arithmetic engine: ATen ops + autograd) ----
+# pinned on the SAME fixtures of the reference's own modules as the numpy oracle above, outputs and every gradient
+
+
+def _tp_grads(pt):
+    return {k: v.grad.numpy() for k, v in pt.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("name", ["perceiver_image", "perceiver_video"])
+def test_torch_port_perceiver(name):
+    import torch
+
+    from oracle import torch_port as TP
+
+    m = G.meta()[name]
+    gold = G.load(name)
+    shapes = synth.perceiver_shapes("perceiver.", m["dim"], m["depth"], num_latents=m["num_latents"], max_num_frames=m["max_num_frames"])
+    pt = TP.to_torch(synth.state_dict_for(m["seed"], shapes))
+    x = torch.from_numpy(synth.tensor(m["seed"], name + ".x", m["xshape"])).requires_grad_(True)
+    y = TP.perceiver_resampler(pt, "perceiver.", x)
+    assert G.rel_err(y.detach().numpy(), gold["y"]) < TOL
+    y.backward(torch.from_numpy(synth.tensor(m["seed"], name + ".R", tuple(y.shape))))
+    assert G.rel_err(x.grad.numpy(), gold["dx"]) < TOL
+    G.check_grads(gold, _tp_grads(pt), TOL)
+
+
+@pytest.mark.parametrize("name", ["xattn_base", "xattn_overflow", "xattn_nomask", "xattn_noprev", "xattn_ge"])
+def test_torch_port_gated_xattn(name):
+    import torch
+
+    from oracle import torch_port as TP
+    from oracle.gen_golden import media_locations
+
+    m = G.meta()[name]
+    gold = G.load(name)
+    pt = TP.to_torch(synth.state_dict_for(m["seed"], synth.gated_xattn_shapes("blk.", m["dim"], m["dim_visual"])))
+    x = torch.from_numpy(synth.tensor(m["seed"], "xattn.x", (2, m["T"], m["dim"]))).requires_grad_(True)
+    media = torch.from_numpy(synth.tensor(m["seed"], "xattn.media", (2, m["T_img"], m["n"], m["dim_visual"]))).requires_grad_(True)
+    ml = None if m["loc_kind"] is None else media_locations(m["loc_kind"], 2, m["T"])
+    with torch.no_grad():
+        a = TP.masked_cross_attention(pt, "blk.attn.", x, media, ml, m["attend_previous"], m["immediate"])
+    assert G.rel_err(a.numpy(), gold["attn_y"]) < TOL
+    y = TP.gated_xattn_block(pt, "blk.", x, media, ml, m["attend_previous"], m["immediate"])
+    assert G.rel_err(y.detach().numpy(), gold["y"]) < TOL
+    y.backward(torch.from_numpy(synth.tensor(m["seed"], "xattn.R", tuple(y.shape))))
+    assert G.rel_err(x.grad.numpy(), gold["dx"]) < TOL
+    assert G.rel_err(media.grad.numpy(), gold["dmedia"]) < TOL
+    G.check_grads(gold, _tp_grads(pt), TOL)
+
+
+def test_torch_port_mpt_block_and_unembed_against_the_pinned_numpy_oracle():
+    """The MPT block and the tied un-embedding + rolled CE of the torch port against the numpy oracle's (pinned through the reference's tiny
+    OTTER-MPT model above, and its attention core through tests/golden/mpt_attn.npz): output, input gradient, loss."""
+    import torch
+
+    from oracle import torch_port as TP
+
+    D, H, S, V = 64, 4, 24, 96
+    p = synth.state_dict_for(11, synth.mpt_block_shapes("m.", D))
+    x = synth.tensor(11, "mpt.x", (2, S, D))
+    R = synth.tensor(11, "mpt.R", (2, S, D))
+    y, c, _ = O.mpt_block_fwd(p, "m.", x, H, O.mpt_attn_bias(H, S, 64))
+    dx = O.mpt_block_bwd_input(p, "m.", R, c)
+    pt = TP.to_torch(p, requires_grad=False)
+    xt = torch.from_numpy(x.copy()).requires_grad_(True)
+    yt = TP.mpt_block(pt, "m.", xt, H, TP.alibi_bias(H, S, 64))
+    assert G.rel_err(yt.detach().numpy(), y) < TOL
+    yt.backward(torch.from_numpy(R.copy()))
+    assert G.rel_err(xt.grad.numpy(), dx) < TOL
+    W = synth.tensor(11, "wte", (V, D), 0.3)
+    labels = np.random.default_rng(3).integers(0, V, size=(2, S))
+    labels[0, :5] = -100
+    loss_np, _ = O.cross_entropy_rolled(y @ W.T, labels)
+    _, loss_t = TP.unembed_loss(torch.from_numpy(y.copy()), torch.from_numpy(W.copy()), labels)
+    assert abs(float(loss_t) - float(loss_np)) < 1e-5 * abs(float(loss_np))

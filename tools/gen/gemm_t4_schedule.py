@@ -47,8 +47,7 @@ def schedule(name, reads, b1, dma, b2, xreads, merged=False):
             parts.append("if (DMA) dma(BUF, (TV) + 2, %d); SB();" % p)
             issued += 1
         if b2 is not None and j == b2:
-            parts.append('if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(%d)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); '
-                         "__builtin_amdgcn_s_barrier(); } SB();" % issued)
+            parts.append("if (NEXT) { T4_WAIT_NEXT(DMA, %d); __builtin_amdgcn_s_barrier(); } SB();" % issued)
         for r in xreads.get(j, []):
             parts.append("if (NEXT) { " + rd(0, r, "(BUF) ^ 1") + " } SB();")
         lines.append("        " + " ".join(parts))
@@ -94,8 +93,7 @@ def schedule_split(name, b1, dma, b2):
             parts.append("if (DMA) dma(BUF, (TV) + 2, %d); SB();" % p)
             issued += 1
         if j == b2:
-            parts.append('if (NEXT) { if (DMA) asm volatile("s_waitcnt vmcnt(%d)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); '
-                         "__builtin_amdgcn_s_barrier(); } SB();" % issued)
+            parts.append("if (NEXT) { T4_WAIT_NEXT(DMA, %d); __builtin_amdgcn_s_barrier(); } SB();" % issued)
         if j >= 96:
             parts.append("if (NEXT) { " + rd2("AB"[j & 1], 0, (j - 96) >> 1, "(BUF) ^ 1") + " } SB();")
         lines.append("        " + " ".join(parts))
@@ -108,15 +106,29 @@ def schedule_split(name, b1, dma, b2):
     return "\n".join(out)
 
 
-DMA_X = {}
-slot = 40
-for p_ in range(16):
-    DMA_X[slot] = [p_]
-    slot += 3 if p_ % 2 == 0 else 4
-X0 = schedule_split("KTILE_X0", 38, DMA_X, 94)
+def dma_x(shift):
+    d, slot = {}, 40 + shift
+    for p_ in range(16):
+        d[slot] = [p_]
+        slot += 3 if p_ % 2 == 0 else 4
+    return d
+
+
+X0 = schedule_split("KTILE_X0", 38, dma_x(0), 94)
 import sys
 if len(sys.argv) > 1 and sys.argv[1] == "x0":
     print(X0)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "inc":
+    # round 6: csrc/gemm_t4_ktile.inc -- the default placement (T0 / X0).  `inc N` adds copies 1..N-1 whose 16 DMA pieces are issued that many
+    # MFMA slots later (KTILE_T0_<s>): the per-wave stagger experiment of round 6 (wave w running copy w so that one piece per MFMA slot
+    # reaches the CU's vector-memory path instead of four every fourth slot) measured NOTHING (370.7 vs 371.1 us, profiles/r06_xt_ab3.txt)
+    # and cost the largest instantiation +15 % (four copies of the K loop: instruction cache); only copy 0 is built.
+    ncopies = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    print("// GENERATED by tools/gen/gemm_t4_schedule.py inc -- do not edit by hand.  KTILE_T0_<s> / KTILE_X0_<s>: s = DMA issue stagger in MFMA slots.")
+    for sh in range(ncopies):
+        print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {40 + 4 * p + sh: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)}))
+        print(schedule_split("KTILE_X0_%d" % sh, 38, dma_x(sh), 94))
     sys.exit(0)
 print(T0)
 print(T1)
