@@ -186,6 +186,20 @@ def lib() -> C.CDLL:
     return l
 
 
+_gemm_debug_word = 0
+
+
+def gemm_set_debug(flags: int) -> int:
+    """otter_gemm_set_debug through a host-side mirror of the word (the C ABI has a setter only): returns the PREVIOUS value so that a caller
+    that borrows a bit -- bench.in_step_gemm_clock's tile stamps -- can put back what the session had set (tile-order / K-order overrides of
+    the A/B tools) instead of clearing it."""
+    global _gemm_debug_word
+    prev = _gemm_debug_word
+    check(lib().otter_gemm_set_debug(int(flags)), "gemm_set_debug")
+    _gemm_debug_word = int(flags)
+    return prev
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().otter_last_error().decode(errors="replace")

@@ -151,7 +151,6 @@ class _SideStream:
     def __init__(self, device):
         self.enabled = device.type == "cuda" and os.environ.get("OTTER_NO_SIDE_STREAM") != "1"
         self.forked = False
-        self._held = []
         if self.enabled:
             key = device.index if device.index is not None else torch.cuda.current_device()
             st = _SideStream._streams.get(key)
@@ -170,19 +169,10 @@ class _SideStream:
 
         return torch.cuda.stream(self.side) if (self.enabled and self.forked) else contextlib.nullcontext()
 
-    def keep(self, *tensors):
-        """Lifetime contract made explicit: a main-stream tensor read by side-stream work must outlive that work.  Named
-        locals of the calling Function do by construction; an inline temporary (e.g. `ops.cast(...)` passed straight into a launch inside
-        `with side.ctx()`) would be returned to the main stream's pool and could be re-used while the side stream still reads it --
-        hand such values to keep(): they are referenced here until join().  Returns its argument(s) for inline use."""
-        self._held.extend(tensors)
-        return tensors[0] if len(tensors) == 1 else tensors
-
     def join(self):
         if self.enabled and self.forked:
             torch.cuda.current_stream().wait_stream(self.side)
             self.forked = False
-        self._held.clear()
 
 
 def _wgrad_rows(dy_rows: torch.Tensor, x_rows: torch.Tensor, gate=None, param=None):

@@ -298,8 +298,10 @@ class TrainStep:
         # OTTER_DP_PERSISTENT=1 keeps the persistent grids (A/B switch).
         from . import _capi as _K
 
+        # (dp_overlap=False: nothing is resident during backward -- the buckets are reduced after it -- so that leg keeps the persistent grids
+        #  and the on / off A/B compares the overlap alone)
         self.grid_mode = _K.GRID_DEFAULT
-        if self.reducer is not None and dev.type == "cuda" and os.environ.get("OTTER_DP_PERSISTENT") != "1":
+        if self.reducer is not None and self.reducer.overlap and dev.type == "cuda" and os.environ.get("OTTER_DP_PERSISTENT") != "1":
             self.grid_mode = _K.GRID_PER_TILE
 
     def close(self):

@@ -206,3 +206,32 @@ def otter_llama_forward_backward(hf, p: dict, spec: O.OtterSpec, vision_x: np.nd
     for q in hf.parameters():
         q.requires_grad_(False)
     return res
+
+
+def fuyu_forward_backward(hf_lm, fuyu_state: dict, ids, patches, patch_indices, labels):
+    """`fuyu_forward` above WITH the backward: transformers' own autograd through the Persimmon decoder (qk-LayerNorm, partial RoPE, squared-ReLU
+    MLP, fuyu/modeling_persimmon.py:191-193,286-310 restates them) and through the patch projection + scatter (fuyu/modeling_fuyu.py:44-77,126).
+    Returns loss, logits and the gradient of EVERY parameter under the product's state-dict names (OtterHD trains all of them)."""
+    own = dict(hf_lm.named_parameters())
+    with torch.no_grad():
+        for k, v in fuyu_state.items():
+            if k.startswith("language_model.") and k[len("language_model."):] in own:
+                own[k[len("language_model."):]].copy_(v.detach().to("cpu", torch.float32))
+    for p_ in hf_lm.parameters():
+        p_.requires_grad_(True)
+        p_.grad = None
+    W = fuyu_state["vision_embed_tokens.weight"].detach().to("cpu", torch.float32).clone().requires_grad_(True)
+    b = fuyu_state["vision_embed_tokens.bias"].detach().to("cpu", torch.float32).clone().requires_grad_(True)
+    ids_t = torch.as_tensor(np.asarray(ids))
+    emb = hf_lm.model.embed_tokens(ids_t)
+    pe = torch.as_tensor(np.asarray(patches), dtype=torch.float32) @ W.t() + b
+    idx = torch.as_tensor(np.asarray(patch_indices))
+    rows = []
+    for bi in range(emb.shape[0]):      # out-of-place form of the reference's in-place scatter (same values; autograd-friendly)
+        dst = torch.nonzero(idx[bi] >= 0, as_tuple=True)[0]
+        rows.append(emb[bi].index_copy(0, dst, pe[bi, idx[bi][dst]]))
+    out = hf_lm(inputs_embeds=torch.stack(rows), labels=torch.as_tensor(np.asarray(labels)))
+    out.loss.backward()
+    g = {"language_model." + k: v.grad.detach().numpy() for k, v in own.items() if v.grad is not None}
+    g["vision_embed_tokens.weight"], g["vision_embed_tokens.bias"] = W.grad.numpy(), b.grad.numpy()
+    return dict(loss=float(out.loss), logits=out.logits.detach().float().numpy(), grads=g)
