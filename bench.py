@@ -132,12 +132,23 @@ def in_step_gemm_clock(one_step):
     buf = np.zeros(512, dtype=np.uint64)
     K_.check(lib.otter_gemm_read_timeline(buf.ctypes.data_as(ctypes.c_void_p), 512), "gemm_read_timeline")
     t = buf.reshape(2, 4, 8, 8).astype(np.int64)[0, 0]          # workgroup 0, wave 0: [tile][mark]
+    words = buf.reshape(2, 4, 8, 8)[0, 0, :, 7]                  # mark 7: shape / operand layout of the launch that stamped the slot
     tiles = [i for i in range(8) if t[i, 0] > 0 and t[i, 4] > t[i, 0] and t[i, 6] > t[i, 5]]
     if not tiles:
         return None
+    # a slot keeps the stamps of the LAST launch that reached it: slot 0 is rewritten by every launch, slots 1-3 only by launches with that many
+    # tiles per workgroup.  The slots are grouped by launch shape and the largest product is reported (in the C2 step: an FFN-shape launch)
+    groups = {}
+    for i in tiles:
+        groups.setdefault(int(words[i]), []).append(i)
+
+    def flops(w):
+        return ((w >> 42) & 0x1fffff) * ((w >> 21) & 0x1fffff) * (w & 0x1fffff)
+
+    w = max(groups, key=flops)
+    tiles = groups[w]
     cyc = float(sum(t[i, 4] - t[i, 0] for i in tiles))
     ticks = float(sum(t[i, 6] - t[i, 5] for i in tiles))
-    w = int(buf.reshape(2, 4, 8, 8)[0, 0, tiles[0], 7])      # mark 7: the shape / operand layout of the launch that left these stamps
     launch = {"M": (w >> 42) & 0x1fffff, "N": (w >> 21) & 0x1fffff, "K": w & 0x1fffff, "a_kmajor": bool(w >> 63), "b_kmajor": bool((w >> 62) & 1)}
     return {"clock_ghz": round(cyc / ticks * 0.1, 3), "tiles": len(tiles), "cycles_per_tile": round(cyc / len(tiles)), "us_per_tile": round(ticks / len(tiles) * 0.01, 1),
             "launch": launch}
@@ -235,7 +246,7 @@ def run_c5(args, device, rank, world, use_dist):
     params = [p for p in model.parameters()]
     opt = FusedAdamW([{"params": [p for p in params if p.ndim >= 2], "weight_decay": 0.1}, {"params": [p for p in params if p.ndim < 2], "weight_decay": 0.0}],
                      lr=1e-5, max_grad_norm=1.0)
-    reducer = GradReducer(params, 1 << 30, overlap=args.dp_overlap == "on") if use_dist else None
+    reducer = GradReducer(params, 1 << 30, overlap=args.dp_overlap == "on", collective=args.dp_collective) if use_dist else None
     B, text_len = args.batch, 64
     grid, P = 36, 36 * 36
     S = grid * (grid + 1) + text_len                      # 1332 image positions (36 rows x (36 patches + newline)) + text
@@ -704,9 +715,16 @@ def main():
     ap.add_argument("--rccl-max-channels", type=int, default=0,
                     help="N > 1: cap RCCL's channel count (NCCL_MAX_NCHANNELS, set before the process group is created): fewer channels = fewer CUs held "
                          "by a resident collective while the backward GEMMs run (0 = RCCL's default; echoed in config)")
+    ap.add_argument("--dp-collective", choices=["all_reduce", "rs_ag"], default="all_reduce",
+                    help="N > 1: average each gradient bucket with one all-reduce (default) or as reduce-scatter + all-gather (GradReducer.collective; "
+                         "SURVEY section 5's 'direct RS + AG' variant) -- echoed in config")
+    ap.add_argument("--rccl-algo", default="",
+                    help="N > 1: NCCL_ALGO for RCCL (e.g. Ring, Tree; empty = RCCL's choice), set before the process group is created -- echoed in config")
     args = ap.parse_args()
     if args.rccl_max_channels > 0:
         os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_max_channels)     # read by RCCL at communicator creation (inherited by spawned ranks)
+    if args.rccl_algo:
+        os.environ["NCCL_ALGO"] = args.rccl_algo
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the ranks ourselves (one process per GPU), exactly the launch the driver uses
@@ -759,7 +777,7 @@ def main():
         ops.set_flash_variant(args.flash_variant)
     model = build_model(device, seed=0, debug_layers=args.debug_layers, config=args.config)  # identical replica on every rank (same seed)
     step = TrainStep(model, lr=1e-5, weight_decay=0.1, max_grad_norm=1.0, autocast_dtype=torch.bfloat16,
-                     force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1", dp_overlap=args.dp_overlap == "on")
+                     force_reducer=os.environ.get("OTTER_FORCE_DIST") == "1", dp_overlap=args.dp_overlap == "on", dp_collective=args.dp_collective)
     B, T = args.batch, args.seq
     from otter_amd.train import masking
 
@@ -874,6 +892,8 @@ def main():
                                      "batch %d per GPU (BASELINE configs[3]), LM+CLIP frozen, bf16 autocast, fp32 masters" % (T, B))),
                        "global_batch": B * world, "seq_len": T, "parallelism": "dp%d" % world,
                        "dp_overlap": args.dp_overlap if use_dist else None,
+                       "dp_collective": args.dp_collective if use_dist else None,
+                       "rccl_algo": (args.rccl_algo or os.environ.get("NCCL_ALGO")) if use_dist else None,
                        "rccl_max_channels": (args.rccl_max_channels or os.environ.get("NCCL_MAX_NCHANNELS")) if use_dist else None,
                        "gemm_grid": "per-tile" if step.grid_mode == 2 else "persistent"},
             "loss": round(float(loss), 4),

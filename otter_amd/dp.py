@@ -24,7 +24,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    def __init__(self, params: List[torch.nn.Parameter], dtype, device):
+    def __init__(self, params: List[torch.nn.Parameter], dtype, device, world: int = 1):
         self.params = params
         # every slice starts on a 256-byte boundary: the weight-gradient GEMMs store into the views with 16-byte vectors
         al = 256 // torch.empty((), dtype=dtype).element_size()
@@ -32,6 +32,9 @@ class _Bucket:
         for p in params:
             offs.append(off)
             off += (p.numel() + al - 1) // al * al
+        # (the reduce-scatter + all-gather form splits the flat buffer into `world` equal shards: length a multiple of world x 256 bytes)
+        off = (off + al * world - 1) // (al * world) * (al * world)
+        self.shard = None                                          # this rank's reduced shard (reduce-scatter + all-gather form only)
         self.flat = torch.zeros(off, dtype=dtype, device=device)   # padding stays zero (zeros reduce to zeros)
         self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
         self.ready = set()   # id(param) whose gradient of the CURRENT backward pass is in its view
@@ -43,7 +46,7 @@ class GradReducer:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 640 << 20,
                  process_group: Optional[dist.ProcessGroup] = None, grad_dtype: torch.dtype = torch.float32, force: bool = False,
-                 row_only: Optional[dict] = None, overlap: Optional[bool] = None):
+                 row_only: Optional[dict] = None, overlap: Optional[bool] = None, collective: Optional[str] = None):
         """row_only: {parameter: row} -- parameters whose gradient is known to be zero outside ONE row when wait() is called
         (the reference's `--mask_lm_head`, train.mask_embedding): they stay out of the buckets, keep an ordinary .grad, and only
         that row is averaged across ranks."""
@@ -56,6 +59,14 @@ class GradReducer:
         import os as _os
 
         self.overlap = (_os.environ.get("OTTER_DP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        # collective="rs_ag" (or OTTER_DP_COLLECTIVE=rs_ag; bench.py --dp-collective): each bucket is averaged as a reduce-scatter into one
+        # shard per rank followed by an all-gather of the shards -- the two halves of a ring all-reduce as separate RCCL calls, which on the
+        # point-to-point xGMI mesh of an MI355X node RCCL may schedule differently from its fused all-reduce ("direct
+        # RS + AG on the 7-link mesh ... compare against stock DDP").  Same averages up to the summation order.  A/B switch for a multi-GPU
+        # session; the default stays one all-reduce per bucket.
+        self.collective = (collective or _os.environ.get("OTTER_DP_COLLECTIVE", "all_reduce")).lower()
+        if self.collective not in ("all_reduce", "rs_ag"):
+            raise ValueError("GradReducer: collective must be 'all_reduce' or 'rs_ag', not %r" % (self.collective,))
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         ps = [p for p in params if p.requires_grad and p not in self.row_only]
         if not ps:
@@ -67,12 +78,12 @@ class GradReducer:
         for p in ps:
             nb = p.numel() * torch.empty((), dtype=grad_dtype).element_size()
             if cur and cur_bytes + nb > bucket_bytes:
-                self.buckets.append(_Bucket(cur, grad_dtype, cur[0].device))
+                self.buckets.append(_Bucket(cur, grad_dtype, cur[0].device, self.world))
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nb
         if cur:
-            self.buckets.append(_Bucket(cur, grad_dtype, cur[0].device))
+            self.buckets.append(_Bucket(cur, grad_dtype, cur[0].device, self.world))
         self._owner = {}
         self._view = {}
         self._hooks = []
@@ -145,6 +156,18 @@ class GradReducer:
 
     def _launch(self, b: _Bucket):
         backend = dist.get_backend(self.group)
+        if self.collective == "rs_ag":
+            n = b.flat.numel() // self.world
+            if b.shard is None:
+                b.shard = torch.empty(n, dtype=b.flat.dtype, device=b.flat.device)
+            if backend == "nccl":     # both calls are enqueued now: RCCL runs them in order on its stream, wait() waits for the second
+                dist.reduce_scatter_tensor(b.shard, b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+                b.work = dist.all_gather_into_tensor(b.flat, b.shard, group=self.group, async_op=True)
+            else:                     # gloo (CPU tests): no stream order between asynchronous calls
+                dist.reduce_scatter_tensor(b.shard, b.flat, op=dist.ReduceOp.SUM, group=self.group)
+                b.shard.div_(self.world)
+                b.work = dist.all_gather_into_tensor(b.flat, b.shard, group=self.group, async_op=True)
+            return
         if backend == "nccl":
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:

@@ -108,6 +108,7 @@ class EmbedRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, ids, weight_data, holder):
         ctx.ids, ctx.holder = ids, holder
+        holder[0].expect(ids.numel())      # the row count of the gradient this lookup will hand to the sink: known now, needed across ranks before apply()
         return F.embedding(ids, weight_data)
 
     @staticmethod

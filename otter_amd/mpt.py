@@ -105,17 +105,25 @@ class _Norm(nn.LayerNorm):
         return OF.fork_layer_norm(x, self.weight, self.bias, self.eps, OF.compute_dtype_for(x))
 
 
+def _own_mode() -> str:
+    """Which GEMMs of the frozen decoder run on csrc/gemm.hip, OTTER_OWN_DECODER_GEMM:
+      "mlp" (the default since round 6): the two products of the frozen MLP that carry a fusion -- up_proj + GELU, down_proj's input gradient
+            + GELU' (functional.FrozenMLPFusedLegsFn) -- so that the decoder's 64 stand-alone GELU / GELU' passes per step (3.4 ms) are gone;
+            the plain products stay on hipBLASLt.  Same-box interleaved A/B, round 6 (cross-tile ring + K-tile rotation in variant 26):
+            126.33 ms per step against 126.73 with the library for all of them (profiles/r06_own_decoder_ab.txt); it was +2.8 % in round 5.
+      "1":  EVERY decoder GEMM on the own kernels (functional.FrozenMLPFn, input gradients against the weights as stored through the K-major
+            kernel: no transposed copies, 13 GB less): +1.2 % on the step (round 5: +4.0 %) -- the library's plain products are still ahead in situ.
+      "0" / "lib": hipBLASLt for all of them + stand-alone GELU kernels (the round 1-5 default; A/B switch)."""
+    v = os.environ.get("OTTER_OWN_DECODER_GEMM", "mlp").lower()
+    return {"1": "all", "mlp": "mlp", "": "mlp"}.get(v, "lib")
+
+
 def _own_gemm() -> bool:
-    """OTTER_OWN_DECODER_GEMM=1: every GEMM of the frozen decoder on csrc/gemm.hip instead of hipBLASLt: fused
-    GELU / GELU' tails in the MLP (functional.FrozenMLPFn), input gradients against the weights as stored (K-major kernel: no transposed
-    copies).  Off by default: measured step time in DESIGN.md section 6 (the library's main loop is still ahead of ours in situ)."""
-    return os.environ.get("OTTER_OWN_DECODER_GEMM") == "1"
+    return _own_mode() == "all"
 
 
 def _own_mlp_fused_legs() -> bool:
-    """OTTER_OWN_DECODER_GEMM=mlp: only the two products of the frozen MLP that carry a fusion (up_proj + GELU, down_proj's input gradient +
-    GELU') on csrc/gemm.hip, the plain products on hipBLASLt (functional.FrozenMLPFusedLegsFn)."""
-    return os.environ.get("OTTER_OWN_DECODER_GEMM") == "mlp"
+    return _own_mode() == "mlp"
 
 
 def _lin(x, w):

@@ -89,6 +89,40 @@ def _worker(rank, world, port, q):
             if p.requires_grad:
                 assert torch.allclose(p.grad, pr.grad, atol=1e-6), n
         red3.close()
+        # collective="rs_ag" (bench.py --dp-collective rs_ag): every bucket as reduce-scatter + all-gather; same averages (another summation
+        # order), views still alias the flat buffers, buckets padded to a multiple of the world size
+        red4 = GradReducer(net.parameters(), bucket_bytes=2048, collective="rs_ag")
+        assert all(b.flat.numel() % world == 0 for b in red4.buckets)
+        for step in range(2):
+            red4.zero_grad()
+            ((net(X[rank::world]) - Y[rank::world]) ** 2).mean().backward()
+            red4.wait()
+            for (n, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+                if p.requires_grad:
+                    assert torch.allclose(p.grad, pr.grad, atol=1e-6), n
+                    assert p.grad.data_ptr() == red4._view[p].data_ptr()
+        red4.close()
+        # SparseEmbedSink with RAGGED row counts (find_and_remove_tokens pads each rank's batch to its own longest sample): the MAX of the
+        # counts is exchanged at forward time (exchange_counts), apply() pads to it without a collective of its own and adds every rank's rows
+        from otter_amd.train import SparseEmbedSink
+
+        V, D = 11, 4
+        emb = torch.nn.Parameter(torch.zeros(V, D))
+        sink = SparseEmbedSink()
+        sink.anchor(emb.device)
+        n_rows = 3 + 2 * rank                                    # 3 rows on rank 0, 5 on rank 1
+        ids = (torch.arange(n_rows) * 2 + rank) % V
+        rows = torch.full((n_rows, D), float(rank + 1))
+        sink.expect(n_rows)
+        sink.exchange_counts(None, world)
+        assert int(sink._nmax[0][0]) == 3 + 2 * (world - 1)
+        sink.add(emb, ids, rows)
+        sink.apply(None, world)
+        want = torch.zeros(V, D)
+        for r in range(world):
+            nr = 3 + 2 * r
+            want.index_add_(0, (torch.arange(nr) * 2 + r) % V, torch.full((nr, D), float(r + 1)), alpha=1.0 / world)
+        assert torch.allclose(emb.grad, want), (emb.grad, want)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

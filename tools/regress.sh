@@ -18,3 +18,6 @@ echo "== flash attention at C2 (tools/flash_bench.py) =="
 timeout 200 python tools/flash_bench.py > $OUT/${TAG}_regress_flash.txt 2>&1; tail -12 $OUT/${TAG}_regress_flash.txt
 echo "== LayerNorm stream kernels, warm / cold (tools/norm_cold_bench.py) =="
 timeout 200 python tools/norm_cold_bench.py > $OUT/${TAG}_regress_norm.txt 2>&1; tail -12 $OUT/${TAG}_regress_norm.txt
+echo "== verdict: this call against the last committed regress table (tools/regress_check.py; non-zero exit on a > 3 % regression on a comparable box) =="
+python tools/regress_check.py $TAG | tee $OUT/${TAG}_regress_check.txt
+exit ${PIPESTATUS[0]}
