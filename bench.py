@@ -137,19 +137,20 @@ def in_step_gemm_clock(one_step):
     if not tiles:
         return None
     # a slot keeps the stamps of the LAST launch that reached it: slot 0 is rewritten by every launch, slots 1-3 only by launches with that many
-    # tiles per workgroup.  The slots are grouped by launch shape and the largest product is reported (in the C2 step: an FFN-shape launch)
+    # tiles per workgroup.  The slots are grouped by launch shape; an FFN-shape launch (N = 16384, K = 4096: the roofline's kernel) is reported when one left stamps, else the largest product
     groups = {}
     for i in tiles:
         groups.setdefault(int(words[i]), []).append(i)
 
     def flops(w):
-        return ((w >> 42) & 0x1fffff) * ((w >> 21) & 0x1fffff) * (w & 0x1fffff)
+        return ((w >> 42) & 0xfffff) * ((w >> 21) & 0x1fffff) * (w & 0x1fffff)
 
-    w = max(groups, key=flops)
+    ffn = [g for g in groups if ((g >> 21) & 0x1fffff, g & 0x1fffff) == (16384, 4096)]      # the roofline's own shape when one of its launches left stamps
+    w = max(ffn or groups, key=flops)
     tiles = groups[w]
     cyc = float(sum(t[i, 4] - t[i, 0] for i in tiles))
     ticks = float(sum(t[i, 6] - t[i, 5] for i in tiles))
-    launch = {"M": (w >> 42) & 0x1fffff, "N": (w >> 21) & 0x1fffff, "K": w & 0x1fffff, "a_kmajor": bool(w >> 63), "b_kmajor": bool((w >> 62) & 1)}
+    launch = {"M": (w >> 42) & 0xfffff, "N": (w >> 21) & 0x1fffff, "K": w & 0x1fffff, "a_kmajor": bool(w >> 63), "b_kmajor": bool((w >> 62) & 1)}   # (M: 20 bits below the two flags)
     return {"clock_ghz": round(cyc / ticks * 0.1, 3), "tiles": len(tiles), "cycles_per_tile": round(cyc / len(tiles)), "us_per_tile": round(ticks / len(tiles) * 0.01, 1),
             "launch": launch}
 

@@ -28,7 +28,7 @@ thread_local char g_otter_err[512] = {0};
 // the one-wave-per-SIMD kernels, blocks 0 and 131, every wave, the first 8 tiles of the block:
 // [block sel 2][wave 4][tile 8][mark 8] -- marks: 0 tile start, 1 prologue done, 2 K loop done, 3 tail done, 4 tile end; variant 26 also
 // stamps the 100 MHz wall clock (s_memrealtime) at tile start (mark 5) and tile end (mark 6): cycles / ticks = the shader clock of that launch,
-// and the launch's shape + operand layout (mark 7: M, N, K in 21 bits each, bits 63 / 62 = A / B K-major).
+// and the launch's shape + operand layout (mark 7: M in 20 bits, N, K in 21 bits each, bits 63 / 62 = A / B K-major).
 __device__ unsigned long long g_gemm_timeline[2 * 4 * 8 * 8];
 
 namespace {
@@ -1610,10 +1610,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + (K_)] = __builtin_amdgcn_s_memtime();  \
             if ((K_) == 0 || (K_) == 4)   /* marks 5 / 6: the 100 MHz wall clock at tile start / end -> shader clock of THIS launch */ \
                 g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + ((K_) == 0 ? 5 : 6)] = wall_clock64();  \
-            if ((K_) == 0)   /* mark 7: which launch this is -- M, N, K (21 bits each) + the operand layout (bits 63 / 62 = A / B K-major) */ \
+            if ((K_) == 0)   /* mark 7: which launch this is -- M (20 bits), N, K (21 bits each) + the operand layout (bits 63 / 62 = A / B K-major) */ \
                 g_gemm_timeline[(((blockIdx.x ? 1 : 0) * 4 + wave) * 8 + tcount) * 8 + 7] =                                     \
                     ((unsigned long long)(TA ? 1 : 0) << 63) | ((unsigned long long)(TB ? 1 : 0) << 62) |                        \
-                    (((unsigned long long)g.M & 0x1fffffull) << 42) | (((unsigned long long)g.N & 0x1fffffull) << 21) | ((unsigned long long)g.K & 0x1fffffull); \
+                    (((unsigned long long)g.M & 0xfffffull) << 42) | (((unsigned long long)g.N & 0x1fffffull) << 21) | ((unsigned long long)g.K & 0x1fffffull); \
         }                                                                                                                 \
     } while (0)
     int tcount = 0;

@@ -69,18 +69,18 @@ gf = 2.0 * M * D * F
 
 def floor_us(name, calls):
     """(floor in us per iteration, what bounds it) for the kernels whose algorithmic work is known at the C2 shape."""
-    if "gemm_bf16_t4_kernel<0, 0, true, true>" in name: return 2 * gf / mf * 1e6, "2 weight gradients 16384x4096x4096, MFMA"
-    if "gemm_bf16_t4_kernel<3, 0, false, true>" in name: return gf / mf * 1e6, "dU = dy W2 with GELU' tail, MFMA"
-    if "gemm_bf16_t4_kernel<1, 0, false, false>" in name: return gf / mf * 1e6, "FF1 forward with GELU tail, MFMA"
-    if "gemm_bf16_t4_kernel<0, 0, false, true>" in name: return gf / mf * 1e6, "df = dU W1, MFMA"
-    if "gemm_bf16_t4_kernel<2, 0, false, false>" in name: return (gf + 2.0 * M * D * 512) / mf * 1e6, "FF2 forward + to_out (gate, fp32 residual), MFMA"
+    if "gemm_bf16_t4_kernel<0, 0, true, true" in name: return 2 * gf / mf * 1e6, "2 weight gradients 16384x4096x4096, MFMA"
+    if "gemm_bf16_t4_kernel<3, 0, false, true" in name: return gf / mf * 1e6, "dU = dy W2 with GELU' tail, MFMA"
+    if "gemm_bf16_t4_kernel<1, 0, false, false" in name: return gf / mf * 1e6, "FF1 forward with GELU tail, MFMA"
+    if "gemm_bf16_t4_kernel<0, 0, false, true" in name: return gf / mf * 1e6, "df = dU W1, MFMA"
+    if "gemm_bf16_t4_kernel<2, 0, false, false" in name: return (gf + 2.0 * M * D * 512) / mf * 1e6, "FF2 forward + to_out (gate, fp32 residual), MFMA"
     if "norm_bwd_dx" in name: return 2 * (M * D * (2 + 4 + 4 + 4)) / bw * 1e6, "2 LayerNorm backward sweeps, HBM"
     if "norm_fwd" in name: return 2 * (M * D * (4 + 2)) / bw * 1e6, "2 LayerNorm forward sweeps, HBM"
     if "norm_bwd_dw_partial" in name: return 2 * (M * D * (2 + 4)) / bw * 1e6, "2 LayerNorm weight-gradient column sums, HBM"
     if "cast_kernel" in name: return calls / n_it * (M * D * 6) / bw * 1e6, "fp32 -> bf16 casts, HBM"
     if "transpose_vec_kernel<unsigned short" in name: return calls / n_it * (M * 512 * 4) / bw * 1e6, "bf16 operand transposes, HBM"
     if "transpose_vec_kernel<float" in name: return (M * D * (4 + 2 + 2)) / bw * 1e6, "dx1 -> bf16 copy + transpose, HBM"
-    if "gemm_bf16_s4h_kernel" in name or "gemm_bf16_s4_kernel" in name or "gemm_bf16_t4_kernel<0, 0, false, false>" in name:
+    if "gemm_bf16_s4h_kernel" in name or "gemm_bf16_s4_kernel" in name or "gemm_bf16_t4_kernel<0, 0, false, false" in name:
         return calls / n_it * (2.0 * M * 512 * D) / mf * 1e6, "skinny projections 4096x512x4096 (or smaller), MFMA"
     return 0.0, ""
 
