@@ -183,8 +183,13 @@ int otter_gemm_set_cu_budget(int cus);
  * workgroup per tile the loss is proportional to the CUs taken (measured).  Costs ~8 us of fixed time per launch
  * when nothing else runs.  Default 1.  Process-wide, set between steps. */
 int otter_gemm_set_persistent(int on);
-/* diagnostics for roofline ablations (results are WRONG when non-zero): bit0 = no global loads inside the K loop,
- * bit1 = no MFMAs.  Never set by the product path. */
+/* Diagnostics and A/B switches of the GEMM kernels, one word.  Never set by the product path.
+ *   bits 0-1  roofline ablations (results are WRONG): bit0 = no global loads inside the K loop, bit1 = no MFMAs
+ *   bit 4 / 6 masked (edge-tile) tail on every tile / tile-phase timeline stamps (otter_gemm_read_timeline); bit 8: 4-wide fused tail
+ *   bits 9-13 tile order of the large-grid kernel (super-tile shape, walk direction; bit 13 = one workgroup per tile)
+ *   bits 14-15 (round 6) cross-tile ring of the large-grid kernel: 0 = process default (on; env OTTER_GEMM_XT), 1 = off, 2 = on
+ *   bits 16-22 + bit 23 (round 6): with bit 23 set, bits 16-22 replace the K-tile order of a tile (default 3 = rotated by the tile's N panel;
+ *             0 = plain: the order the bit-for-bit comparisons against other kernels use; env OTTER_GEMM_KORDER sets the process default) */
 int otter_gemm_set_debug(int flags);
 
 /* out[0] (op) = scale(gate) * sum(partial[0..n))   with scale = (1 - tanh(*gate)^2) when gate != NULL.
@@ -406,7 +411,8 @@ int otter_prof_arm_gemm(int64_t M, int64_t N, int64_t K, int max_events);
 /* Diagnostics: with otter_gemm_set_debug bit 64 set, the one-wave-per-SIMD bf16 kernels (variants 18-20) record shader-clock
  * timestamps at their tile-phase boundaries for two blocks; this copies the first n of the 512 uint64 slots
  * ([block 2][wave 4][tile 8][mark 8]: 0 tile start, 1 prologue done, 2 K loop done, 3 tail done, 4 tile end; the large-grid kernel also
- * stamps the 100 MHz wall clock at tile start / end in marks 5 / 6: the shader clock of that very launch) to the host. */
+ * stamps the 100 MHz wall clock at tile start / end in marks 5 / 6: the shader clock of that very launch, and the launch's shape and operand
+ * layout in mark 7: M << 42 | N << 21 | K, bits 63 / 62 = A / B K-major) to the host. */
 int otter_gemm_read_timeline(unsigned long long* out, int n);
 int otter_prof_disarm(void);
 int otter_prof_collect(int* count, double* total_ms);
