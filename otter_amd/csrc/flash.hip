@@ -37,6 +37,9 @@ constexpr int LDT = HD + 32;  // transpose-read tiles (320-B rows)
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
+#ifndef OTTER_FLASH_DMA_SPREAD
+#define OTTER_FLASH_DMA_SPREAD 0
+#endif
 #ifndef OTTER_FLASH_ROWSTORE
 #define OTTER_FLASH_ROWSTORE 1   // O, dQ and the per-block dK / dV leave through an LDS transpose as whole 256-byte rows (store_rows_lds), like dK / dV of the
                                  // persistent kernel; 0 (A/B builds) = the 8-byte-per-row stores of store_dt.  Round 4, C2: forward 43.9 -> 41.7 us
@@ -511,13 +514,18 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         __builtin_amdgcn_s_barrier();  // tile kt has landed for every wave; every wave is done with tile kt-1
         asm volatile("" ::: "memory");
         FSTAMP(2 + 5 * kt);
-        if (kt + 1 < nkt)
-            flash_dma_tile(rk, rv, smem + (cur ^ 1) * 16384, smem + 32768 + (cur ^ 1) * 16384, vk, vv, wave, (uint32_t)(kt + 1) * 64u * krow,
-                           (uint32_t)(kt + 1) * 64u * vrow);
-        FSTAMP(3 + 5 * kt);
         const int k0 = kt * 64;
         const int wq0 = q0 + wave * 32 + off;  // first query of the wave, in key coordinates
-        if (a.causal && k0 > wq0 + 31) continue;  // whole tile above this wave's diagonal
+        // OTTER_FLASH_DMA_SPREAD (round 6 experiment): the eight DMA pieces of tile kt + 1 are issued between the MFMAs of S = K Q^T instead of
+        // in one burst behind the barrier (the burst takes ~480 cycles of a 4 400-cycle tile, profiles/r04_flash_block0_timeline.txt)
+        const bool dma_next = kt + 1 < nkt;
+        const bool skip_tile = a.causal && k0 > wq0 + 31;   // whole tile above this wave's diagonal
+        char* const kdn = smem + (cur ^ 1) * 16384;
+        char* const vdn = smem + 32768 + (cur ^ 1) * 16384;
+        const uint32_t ksn = (uint32_t)(kt + 1) * 64u * krow, vsn = (uint32_t)(kt + 1) * 64u * vrow;
+        if (dma_next && (!OTTER_FLASH_DMA_SPREAD || PAIR || skip_tile)) flash_dma_tile(rk, rv, kdn, vdn, vk, vv, wave, ksn, vsn);
+        FSTAMP(3 + 5 * kt);
+        if (skip_tile) continue;
         const char* Kc = smem + cur * 16384;
         const char* Vc = smem + 32768 + cur * 16384;
         if constexpr (PAIR) {
@@ -614,9 +622,17 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         for (int kbk = 0; kbk < 2; ++kbk) {
             s[kbk] = zero16();
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+            for (int c = 0; c < 8; ++c) {
                 s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                     *reinterpret_cast<const bf16x8_t*>(Kc + kbk * 8192 + (kfo ^ (32 * c))), qf[c], s[kbk], 0, 0, 0);
+                if constexpr (OTTER_FLASH_DMA_SPREAD != 0) {
+                    if ((c & 1) && dma_next) {      // piece i of K behind MFMAs 1, 3, 5, 7 of the first key block, of V behind those of the second
+                        const int i = c >> 1;
+                        if (kbk == 0) dma16_asm(rk, kdn + (wave * 4 + i) * 1024, vk[i], ksn);
+                        else dma16_asm(rv, vdn + (wave * 4 + i) * 1024, vv[i], vsn);
+                    }
+                }
+            }
         }
         const float base = sl2 * (float)(k0 + 4 * h2 - (a.Sk - 1));
         float mx = -INFINITY;
