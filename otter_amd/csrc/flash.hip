@@ -38,7 +38,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
 #ifndef OTTER_FLASH_DMA_SPREAD
-#define OTTER_FLASH_DMA_SPREAD 0
+#define OTTER_FLASH_DMA_SPREAD 1   // forward (128-wide): DMA pieces of the next tile between the S MFMAs, not in a burst: 41.1-41.3 -> 39.6-40.2 us at C2 (round 6; 0 = A/B build)
 #endif
 #ifndef OTTER_FLASH_ROWSTORE
 #define OTTER_FLASH_ROWSTORE 1   // O, dQ and the per-block dK / dV leave through an LDS transpose as whole 256-byte rows (store_rows_lds), like dK / dV of the
@@ -516,8 +516,8 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         FSTAMP(2 + 5 * kt);
         const int k0 = kt * 64;
         const int wq0 = q0 + wave * 32 + off;  // first query of the wave, in key coordinates
-        // OTTER_FLASH_DMA_SPREAD (round 6 experiment): the eight DMA pieces of tile kt + 1 are issued between the MFMAs of S = K Q^T instead of
-        // in one burst behind the barrier (the burst takes ~480 cycles of a 4 400-cycle tile, profiles/r04_flash_block0_timeline.txt)
+        // OTTER_FLASH_DMA_SPREAD (round 6): the eight DMA pieces of tile kt + 1 are issued between the MFMAs of S = K Q^T instead of in one
+        // burst behind the barrier (the burst took ~480 cycles of a 4 400-cycle tile, profiles/r04_flash_block0_timeline.txt): -3 % per launch
         const bool dma_next = kt + 1 < nkt;
         const bool skip_tile = a.causal && k0 > wq0 + 31;   // whole tile above this wave's diagonal
         char* const kdn = smem + (cur ^ 1) * 16384;
@@ -1349,12 +1349,16 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 1 < nkt)
-            flash_dma_tile(rk, rv, smem + (cur ^ 1) * 16384, smem + 32768 + (cur ^ 1) * 16384, vk, vv, wave, (uint32_t)(kt + 1) * 64u * krow,
-                           (uint32_t)(kt + 1) * 64u * vrow);
         const int k0 = kt * 64;
         const int wq0 = q0 + wave * 32 + off;
-        if (a.causal && k0 > wq0 + 31) continue;
+        // (the forward's spread of the DMA pieces over the MFMAs was tried here too in round 6: 137-138 vs 133-134 us per backward -- not kept)
+        const bool dma_next = kt + 1 < nkt;
+        const bool skip_tile = a.causal && k0 > wq0 + 31;
+        char* const kdn = smem + (cur ^ 1) * 16384;
+        char* const vdn = smem + 32768 + (cur ^ 1) * 16384;
+        const uint32_t ksn = (uint32_t)(kt + 1) * 64u * krow, vsn = (uint32_t)(kt + 1) * 64u * vrow;
+        if (dma_next) flash_dma_tile(rk, rv, kdn, vdn, vk, vv, wave, ksn, vsn);
+        if (skip_tile) continue;
         const char* Kc = smem + cur * 16384;
         const char* Vc = smem + 32768 + cur * 16384;
         const int kend = a.Sk - 1 - k0, rel = qi + off - k0;
