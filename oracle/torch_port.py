@@ -51,11 +51,10 @@ def perceiver_block(p, pre, x, latents, heads=8):
     k, v = kv.chunk(2, dim=-1)
     q, k, v = _heads(q, heads), _heads(k, heads), _heads(v, heads)
     q = q * (q.shape[-1] ** -0.5)
-    sim = torch.einsum("... i d, ... j d  -> ... i j", q, k)
-    sim = sim - sim.amax(dim=-1, keepdim=True).detach()
-    attn = sim.softmax(dim=-1)
-    out = torch.einsum("... i j, ... j d -> ... i d", attn, v)
-    out1 = F.linear(_merge(out), p[pre + "to_out.weight"]) + latents
+    scores = torch.matmul(q, k.transpose(-1, -2))                  # (the reference spells the two products as einsums: the same bmm kernels)
+    scores = scores - scores.amax(-1, keepdim=True).detach()       # :176 -- the shift is detached in the reference too
+    probs = torch.softmax(scores, dim=-1)
+    out1 = F.linear(_merge(torch.matmul(probs, v)), p[pre + "to_out.weight"]) + latents
     f = F.layer_norm(out1, (D,), p[pre + "feed_forward.0.weight"], p[pre + "feed_forward.0.bias"])
     return F.linear(F.gelu(F.linear(f, p[pre + "feed_forward.1.weight"])), p[pre + "feed_forward.3.weight"]) + out1
 
@@ -86,7 +85,7 @@ def masked_cross_attention(p, pre, x, media, media_locations=None, attend_previo
     k, v = kv.chunk(2, dim=-1)
     q, k, v = _heads(q, heads), _heads(k, heads), _heads(v, heads)
     q = q * (q.shape[-1] ** -0.5)
-    sim = torch.einsum("... i d, ... j d -> ... i j", q, k)
+    scores = torch.matmul(q, k.transpose(-1, -2))
     text_time = None
     if media_locations is not None:
         ml = torch.as_tensor(media_locations, dtype=torch.bool)
@@ -98,13 +97,12 @@ def masked_cross_attention(p, pre, x, media, media_locations=None, attend_previo
             text_time[text_time > ml.sum(-1, keepdim=True).expand_as(text_time)] = 0
         op = torch.eq if only_attend_immediate_media else torch.ge             # :313-319
         allowed = op(text_time[:, None, :, None], media_time.repeat_interleave(n)[None, None, None, :])
-        sim = sim.masked_fill(~allowed, -torch.finfo(sim.dtype).max)           # :321
-    sim = sim - sim.amax(dim=-1, keepdim=True).detach()                        # :323
-    attn = sim.softmax(dim=-1)
-    if media_locations is not None and only_attend_immediate_media:           # :326-330
-        attn = attn.masked_fill((text_time == 0)[:, None, :, None], 0.0)
-    out = torch.einsum("... i j, ... j d -> ... i d", attn, v)
-    return F.linear(_merge(out), p[pre + "to_out.weight"])
+        scores = scores.masked_fill(~allowed, -torch.finfo(scores.dtype).max)  # :321 (finite fill BEFORE the shift)
+    scores = scores - scores.amax(-1, keepdim=True).detach()                   # :323
+    probs = torch.softmax(scores, dim=-1)
+    if media_locations is not None and only_attend_immediate_media:           # :326-330: rows without a preceding image are zeroed
+        probs = probs.masked_fill((text_time == 0)[:, None, :, None], 0.0)
+    return F.linear(_merge(torch.matmul(probs, v)), p[pre + "to_out.weight"])
 
 
 def gated_xattn_block(p, pre, x, media, media_locations=None, attend_previous=True, only_attend_immediate_media=True, heads=8):
