@@ -14,6 +14,8 @@ epi = sys.argv[1] if len(sys.argv) > 1 else "store"
 km = sys.argv[2] if len(sys.argv) > 2 else "0"
 M, N, Kd = 4096, 16384, 4096
 NSET = 8
+if os.environ.get("CU_BUDGET"):      # round 6: persistent grid on fewer CUs -- do the tails shorten when fewer CUs write at once?
+    print("persistent workgroups:", ops.set_gemm_cu_budget(int(os.environ["CU_BUDGET"])))
 bf = torch.bfloat16
 AMP = float(os.environ.get("AMP", "0.05"))      # AMP=0: zero operands (no data-dependent power: is the K loop bound by the clock or by the memory path?)
 As = [(torch.randn(M, Kd, device="cuda") * AMP).to(bf) for _ in range(NSET)]
