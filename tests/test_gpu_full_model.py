@@ -13,7 +13,7 @@ blocks + 24 CLIP layers + 6 perceiver layers, not weight rounding.
   (ii) bf16 production mode (frozen weights bf16, bf16 autocast: the kernels the benchmark runs): drift REPORTED (per-row error, cosine,
        loss, greedy agreement, and the fp32 top-2 margin of every greedy step -- gpurun_out/parity_metrics.jsonl -> profiles/, DESIGN.md
        section 5) and bounded by the stated tolerances below.
-  (iii) C2-shaped batch (B x 512 tokens, B = OTTER_G1_C2_BATCH, default 8 = the bench batch since round 6): bf16 loss and per-row logits vs the oracle.
+  (iii) C2-shaped batch (B x 512 tokens, B = OTTER_G1_C2_BATCH, default 4 since round 6; 8 = the bench batch): bf16 loss and per-row logits vs the oracle.
   (iv) THE TRAINING STEP (round 5, VERDICT r4 item 1 -- the metric is a training step, not a forward): the composed backward through
        all 32 layers (flash dQ/dK/dV or the fp32 cores, K-major dgrad / wgrad GEMMs, fork-LayerNorm, the deferred residual add,
        SparseEmbedSink, weight gradients) + grad-norm clip + FusedAdamW of otter_amd.train.TrainStep on a 2 x 128-token batch (several
@@ -439,7 +439,7 @@ def test_c2_batch_bf16_loss_and_logits_vs_oracle(full):
     """The bench shape (512 tokens per pair), bf16 production mode, forward: loss and logits of B pairs vs the fp32 oracle on the host."""
     model, bench = full["model"], full["bench"]
     assert next(p for p in model.parameters() if not p.requires_grad).dtype == torch.bfloat16, "runs after the bf16 C1 leg"
-    B = int(os.environ.get("OTTER_G1_C2_BATCH", "8"))        # the benchmark's own batch (r6; ~2.5 min of host oracle on 256 threads); smaller boxes: OTTER_G1_C2_BATCH=2
+    B = int(os.environ.get("OTTER_G1_C2_BATCH", "4"))        # r6: 4 (about a minute of host oracle on 256 threads; the GPU suite has a wall-clock limit); 8 = the benchmark's own batch, whose training step the bench-shape legs below cover
     vision_x, ids, mask, labels, _ = bench.synth_batch(model, B, 512, DEV, seed=977)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out = model(vision_x=vision_x.to(torch.bfloat16), lang_x=ids, attention_mask=mask, labels=labels)
