@@ -108,6 +108,9 @@ int otter_rmsnorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
  * Replaces every bias-free nn.Linear on the path (modeling_otter.py:139-141,145,147,255-257,366,368) with the
  * element-wise tail that follows it fused into the epilogue:
  *   OTTER_EPI_STORE     C = s * acc                      (s = tanh(*gate) if gate else 1; accumulate: C += ...)
+ *                       with an fp32 C and partial != NULL also partial[block] = sum over the tile of C^2 (the values as stored): the
+ *                       clip_grad_norm_ reduction of a weight gradient (pipeline/train/instruction_following.py:246-247) taken in the
+ *                       producing launch instead of by a second sweep over the tensor; summed by otter_clip_coef like any other partial.
  *   OTTER_EPI_GELU      C = gelu_erf(acc); C2 = acc       (Linear -> nn.GELU, :366-367 / :145-146; C2 optional)
  *   OTTER_EPI_SCALE_RES C = acc * s + R                  (x = attn(...) * attn_gate.tanh() + x, :380-393;
  *                                                          gate == NULL gives the perceiver's plain residual :180,184)
@@ -134,7 +137,7 @@ typedef struct {
     int64_t ldaux;
     int aux_dtype;
     int aux_is_gelu_input; /* 0 identity, 1 erf GELU, 2 squared ReLU */
-    float* partial;      /* GATE_BWD: [otter_gemm_num_partials(M,N)] floats, or NULL */
+    float* partial;      /* GATE_BWD, STORE with an f32 C: [otter_gemm_num_partials(M,N)] floats, or NULL */
     int grid_mode;       /* otter_grid_mode of THIS launch (ABI 2): how the large-grid kernel maps tiles to workgroups */
 } otter_epilogue_args;
 

@@ -40,6 +40,11 @@ constexpr float LN2 = 0.6931471805599453f;
 #ifndef OTTER_FLASH_DMA_SPREAD
 #define OTTER_FLASH_DMA_SPREAD 1   // forward (128-wide): DMA pieces of the next tile between the S MFMAs, not in a burst: 41.1-41.3 -> 39.6-40.2 us at C2 (round 6; 0 = A/B build)
 #endif
+#ifndef OTTER_FLASH_PRIO
+#define OTTER_FLASH_PRIO 0   // A/B builds: s_setprio 1 around the MFMA clusters (bit 0 forward, bit 1 dQ, bit 2 dK/dV): the two workgroups of a CU are not
+                             // in step with each other, so a wave in its matrix segment may take the issue slots of its neighbour's softmax
+#endif
+#define FPRIO(BIT_, P_) do { if constexpr ((OTTER_FLASH_PRIO & (BIT_)) != 0) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(P_); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #ifndef OTTER_FLASH_ROWSTORE
 #define OTTER_FLASH_ROWSTORE 1   // O, dQ and the per-block dK / dV leave through an LDS transpose as whole 256-byte rows (store_rows_lds), like dK / dV of the
                                  // persistent kernel; 0 (A/B builds) = the 8-byte-per-row stores of store_dt.  Round 4, C2: forward 43.9 -> 41.7 us
@@ -618,6 +623,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
             continue;
         }
         f32x16_t s[2];
+        FPRIO(1, 1);
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
             s[kbk] = zero16();
@@ -634,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
                 }
             }
         }
+        FPRIO(1, 0);
         const float base = sl2 * (float)(k0 + 4 * h2 - (a.Sk - 1));
         float mx = -INFINITY;
         const bool interior = kv == nullptr && k0 + 63 < a.Sk && (!a.causal || k0 + 63 <= wq0);
@@ -700,6 +707,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
         asm volatile("" :: "v"(s[1][15]), "v"(lsum));
 #endif
         FSTAMP(4 + 5 * kt);
+        FPRIO(1, 1);
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
@@ -714,6 +722,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd2_kernel(FlashArgs a) {
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vfr), pf, o[db], 0, 0, 0);
                 }
             }
+        FPRIO(1, 0);
         FSTAMP(5 + 5 * kt);
     }
     FSTAMP(90);
@@ -1413,11 +1422,13 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
             f32x16_t s = zero16(), dp = zero16();
+            FPRIO(2, 1);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Kc + kbk * 8192 + (kfo ^ (32 * c))), qf[c], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8_t*>(Vc + kbk * 8192 + (vfo ^ (32 * c))), dof[c], dp, 0, 0, 0);
             }
+            FPRIO(2, 0);
             if (interior) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1438,6 +1449,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
                     s[r] = p * (dp[r] - dl);
                 }
             }
+            FPRIO(2, 1);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const bf16x8_t dsf = pack8(s, 8 * c);
@@ -1445,6 +1457,7 @@ __global__ __launch_bounds__(256, 2) void flash_bwd_dq2_kernel(FlashArgs a) {
                 for (int db = 0; db < 4; ++db)
                     dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pi_frag(Kc, to1, to2, db, 32 * kbk + 16 * c), dsf, dq[db], 0, 0, 0);
             }
+            FPRIO(2, 0);
         }
     }
     if constexpr (PAIR) {

@@ -122,7 +122,17 @@ __device__ __forceinline__ float gelu_bwd_apply(bool fast, float s, const float 
     return part;
 }
 
-// epilogue on 4 consecutive output columns of row m; returns this thread's contribution to the gate partial
+// Plain-store launches with an fp32 C (weight gradients) can also hand back sum(C^2) per tile -- the clip_grad_norm_ reduction of that tensor,
+// taken while the values are in registers instead of by a second 4-byte-per-element sweep over it (otter_epilogue_args::partial, round 6b).
+template <int NE>
+__device__ __forceinline__ float sumsq_of(const float (&o)[NE]) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) t = fmaf(o[i], o[i], t);
+    return t;
+}
+
+// epilogue on 4 consecutive output columns of row m; returns this thread's contribution to the gate partial (plain store, fp32 C: to sum(C^2))
 template <int EPI>
 __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m, int64_t n, float (&v)[4]) {
     float part = 0.f;
@@ -139,6 +149,7 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
                 for (int i = 0; i < 4; ++i) o[i] = s * v[i];
             }
             store4(g.C, m * g.ldc + n, g.cdt, o);
+            if (g.cdt == OTTER_F32) part = sumsq_of<4>(o);   // (written out only when the launch asked for partials: block_partial)
             break;
         }
         case OTTER_EPI_GELU: {
@@ -220,6 +231,7 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = s * v[i];
             }
+            if (g.cdt == OTTER_F32) part = sumsq_of<8>(o);
             break;
         }
         case OTTER_EPI_GELU: {
@@ -329,7 +341,7 @@ __device__ __forceinline__ void park_block(float* __restrict__ blk, const f32x16
 // deterministic block reduction of the per-thread partial into partial[blockIdx.x]
 template <int NWAVES, int EPI>
 __device__ __forceinline__ void block_partial(const GemmArgs& g, float part, float* red /* LDS, >= NWAVES floats */, int slot) {
-    if (EPI != OTTER_EPI_GATE_BWD || g.partial == nullptr) return;
+    if ((EPI != OTTER_EPI_GATE_BWD && EPI != OTTER_EPI_STORE) || g.partial == nullptr) return;
     part = wave_sum(part);
     __syncthreads();  // everyone is done with the LDS that `red` aliases
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -402,6 +414,7 @@ __device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t 
 #pragma unroll
             for (int i = 0; i < NE; ++i) o[i] = s * v[i];
         }
+        if (g.cdt == OTTER_F32) part = sumsq_of<NE>(o);   // (g.cdt is a compile-time constant in the full-tile tails: bf16 stores carry nothing extra)
     } else if constexpr (EPI == OTTER_EPI_GELU) {
         if (g.C2) {
             if constexpr (NE == 8) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
@@ -1986,7 +1999,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         if constexpr (XT) {
             // no drain: the stores stay in flight (iteration 1 of the next tile is the first wait that counts them).  The gate partial's
             // cross-wave sum goes through the first word of each wave's own parking stripe (dead: its tail is over)
-            if (EPI == OTTER_EPI_GATE_BWD && g.partial != nullptr) {
+            if ((EPI == OTTER_EPI_GATE_BWD || EPI == OTTER_EPI_STORE) && g.partial != nullptr) {
                 float* red = reinterpret_cast<float*>(smem + XT_PARK);
                 part = wave_sum(part);
                 if (lane == 0) red[wave * (XPARK_BYTES / 4)] = part;
@@ -2847,12 +2860,14 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
     switch (g.kind) {
         case OTTER_EPI_STORE:
             OTTER_REQUIRE(!g.accumulate || c_dtype == OTTER_F32, "gemm: accumulate needs an f32 C");
+            OTTER_REQUIRE(!g.partial || c_dtype == OTTER_F32, "gemm: sum-of-squares partials of a plain store need an f32 C");
             break;
         case OTTER_EPI_GELU:
             OTTER_REQUIRE(!g.C2 || g.ldc2 % 4 == 0, "gemm: ldc2 %% 4");
             break;
         case OTTER_EPI_SCALE_RES:
             OTTER_REQUIRE(g.R && g.ldr % 4 == 0, "gemm: SCALE_RES needs R with ldr %% 4 == 0");
+            OTTER_REQUIRE(!g.partial, "gemm: partials are written by the STORE (fp32 C) and GATE_BWD epilogues only");
             break;
         case OTTER_EPI_GATE_BWD:
             OTTER_REQUIRE(g.aux && g.ldaux % 4 == 0, "gemm: GATE_BWD needs aux with ldaux %% 4 == 0");
@@ -2868,9 +2883,9 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
     // round 4: few 128 x 128 tiles of the ring kernel -> half-height tiles (variant 30), so that the skinny products (128 tiles or fewer on
     // 256 CUs) stream on twice the CUs.  Not for a launch that writes per-block gate partials (their count follows otter_gemm_num_partials).
     // OTTER_NO_S4H=1 (read once): A/B switch.
-    if (cfg == CFG_S4 && g_variant == 0 && !s4h_off() && cdiv64(M, 128) * cdiv64(N, 128) <= 160 && !(g.kind == OTTER_EPI_GATE_BWD && g.partial))
+    if (cfg == CFG_S4 && g_variant == 0 && !s4h_off() && cdiv64(M, 128) * cdiv64(N, 128) <= 160 && !g.partial)
         cfg = CFG_S4H;
-    if (cfg == CFG_S4H && g.kind == OTTER_EPI_GATE_BWD && g.partial) cfg = CFG_S4;   // (a forced variant 30)
+    if (cfg == CFG_S4H && g.partial) cfg = CFG_S4;   // (a forced variant 30)
     g.ta = a_kmajor; g.tb = b_kmajor;
     int bm, bn;
     cfg_tiles(cfg, bm, bn);

@@ -101,6 +101,64 @@ grad_sink = None
 embed_sink = None
 
 
+# Set by train.TrainStep on a single rank (round 6b): the clip_grad_norm_ reduction of a weight gradient is taken INSIDE the GEMM that
+# produces it (otter_epilogue_args::partial with a plain fp32 store: sum(dW^2) per output tile while the values are in registers) instead
+# of by the optimizer's 4-byte-per-parameter sweep over every gradient.  Interface: slot(param, n) -> fp32 [n] buffer for the launch's
+# partials, commit(param, grad_tensor).  The optimizer (optim.FusedAdamW) takes a tensor's fused partials only if the parameter's .grad
+# still IS that launch's output, untouched (data pointer and version counter) -- anything else falls back to the sweep.
+norm_sink = None
+
+
+class GradNormSink:
+    """Per-step registry of weight gradients whose sum of squares was produced by their own GEMM launch."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+        self.entries = {}     # id(param) -> (offset, n, data_ptr, version, numel)
+
+    def begin(self):
+        self.used = 0
+        self.entries.clear()
+
+    def slot(self, param, n: int):
+        if id(param) in self.entries:          # a second weight-gradient launch for the same parameter (shared weight): not fusable
+            self.entries[id(param)] = None
+            return None
+        if self.buf is None or self.used + n > self.buf.numel():
+            if self.used:                      # a live step never moves its buffer: launches already hold pointers into it
+                return None
+            self.buf = torch.empty(max(1 << 16, 2 * n), dtype=torch.float32, device=param.device)
+        off = self.used
+        self.used += n
+        self.entries[id(param)] = (off, n, 0, 0, 0)
+        return self.buf[off:off + n]
+
+    def commit(self, param, grad: torch.Tensor):
+        e = self.entries.get(id(param))
+        if e is not None:
+            self.entries[id(param)] = (e[0], e[1], grad.data_ptr(), grad._version, grad.numel())
+
+    def fused(self, param):
+        """(offset, n) if `param.grad` is still exactly what the committed launch wrote, else None."""
+        e = self.entries.get(id(param))
+        g = param.grad
+        if e is None or g is None or e[2] == 0:
+            return None
+        if g.data_ptr() != e[2] or g._version != e[3] or g.numel() != e[4] or g.dtype != torch.float32 or not g.is_contiguous():
+            return None
+        return e[0], e[1]
+
+
+def _wgrad_fused_norm(launch, M, N, dtype, param):
+    """Run a weight-gradient launch (`launch(partial)` -> fp32 tensor) with its sum-of-squares partials handed to norm_sink."""
+    part = norm_sink.slot(param, ops.gemm_num_partials(M, N, dtype))
+    res = launch(part)
+    if part is not None:
+        norm_sink.commit(param, res)
+    return res
+
+
 class EmbedRowsFn(torch.autograd.Function):
     """rows = weight[ids] with the gradient routed to `embed_sink` instead of to the parameter's autograd leaf (the weight enters detached;
     the 0-d `anchor` only makes the output differentiable so that backward runs)."""
@@ -135,6 +193,9 @@ def _wgrad(dyT: torch.Tensor, xT: torch.Tensor, gate=None, param=None):
         ops.gemm_nt(dyT, xT, out=out, kind=EPI_STORE, gate=gate)
         grad_sink.ready(param)
         return None
+    if norm_sink is not None and param is not None:
+        return _wgrad_fused_norm(lambda part: ops.gemm_nt(dyT, xT, out_dtype=torch.float32, kind=EPI_STORE, gate=gate, partial=part),
+                                 dyT.shape[0], xT.shape[0], dyT.dtype, param)
     return ops.gemm_nt(dyT, xT, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
 
 
@@ -189,6 +250,9 @@ def _wgrad_rows(dy_rows: torch.Tensor, x_rows: torch.Tensor, gate=None, param=No
             ops.gemm(dy_rows, x_rows, True, True, out=out, kind=EPI_STORE, gate=gate)
             grad_sink.ready(param)
             return None
+        if norm_sink is not None and param is not None:
+            return _wgrad_fused_norm(lambda part: ops.gemm(dy_rows, x_rows, True, True, out_dtype=torch.float32, kind=EPI_STORE, gate=gate,
+                                                           partial=part), n_out, n_in, dy_rows.dtype, param)
         return ops.gemm(dy_rows, x_rows, True, True, out_dtype=torch.float32, kind=EPI_STORE, gate=gate)
     cd = dy_rows.dtype
     return _wgrad(ops.transpose(dy_rows, cd), ops.transpose(x_rows, cd), gate=gate, param=param)

@@ -32,6 +32,8 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.max_grad_norm = max_grad_norm
         self.refresh_shadows = True
+        self.norm_sink = None  # functional.GradNormSink (train.TrainStep, single rank): gradients whose sum of squares came out of their own GEMM
+        self.fused_norm_tensors = 0   # how many gradients of the last step took their sum of squares from the producing launch
         self._tables = None
         self.last_norm = None  # device tensor [2]: total gradient norm, clip coefficient
 
@@ -57,7 +59,7 @@ class FusedAdamW(torch.optim.Optimizer):
         bt, bc = np.concatenate(bt), np.concatenate(bc)
         meta = np.zeros(len(live), dtype=_META)
         self._tables = dict(key=[(id(p), p.numel()) for p, _, _ in live], meta=meta, nblocks=int(bt.size),
-                            bt=torch.from_numpy(bt).to(dev), bc=torch.from_numpy(bc).to(dev),
+                            bt=torch.from_numpy(bt).to(dev), bc=torch.from_numpy(bc).to(dev), bt_host=bt, bc_host=bc, sweeps={},
                             partials=torch.empty(int(bt.size), dtype=torch.float32, device=dev),
                             dmeta=torch.empty(meta.nbytes, dtype=torch.uint8, device=dev),
                             hmeta=torch.empty(meta.nbytes, dtype=torch.uint8).pin_memory(),
@@ -130,9 +132,33 @@ class FusedAdamW(torch.optim.Optimizer):
         lib, stm = K.lib(), K.stream()
         scale = None
         if self.max_grad_norm is not None:
-            K.check(lib.otter_grad_sumsq(t["dmeta"].data_ptr(), t["bt"].data_ptr(), t["bc"].data_ptr(), t["nblocks"], t["partials"].data_ptr(), stm),
-                    "grad_sumsq")
-            K.check(lib.otter_clip_coef(t["partials"].data_ptr(), t["nblocks"], float(self.max_grad_norm), t["norm"].data_ptr(), stm), "clip_coef")
+            # Gradients whose sum of squares was written by the GEMM that produced them (functional.GradNormSink; verified against the
+            # tensor .grad holds NOW) leave the sweep: their per-tile partials are appended behind the sweep's per-block partials and
+            # otter_clip_coef adds up both.  At OTTER-MPT7B that is the sixteen FFN matrices of the gated blocks, 88 % of the 4.9 GB sweep.
+            sink, fused = self.norm_sink, {}
+            if sink is not None and sink.buf is not None:
+                for i, (p, _, _) in enumerate(live):
+                    f = sink.fused(p)
+                    if f is not None:
+                        fused[i] = f
+            self.fused_norm_tensors = len(fused)
+            bt_d, bc_d, n_sweep, parts, n_parts = t["bt"], t["bc"], t["nblocks"], t["partials"], t["nblocks"]
+            if fused:
+                key = tuple(sorted(fused))
+                sw = t["sweeps"].get(key)
+                if sw is None:
+                    keep = ~np.isin(t["bt_host"], np.asarray(key, dtype=np.int32))
+                    dev = t["bt"].device
+                    sw = t["sweeps"][key] = (torch.from_numpy(t["bt_host"][keep]).to(dev), torch.from_numpy(t["bc_host"][keep]).to(dev), int(keep.sum()))
+                bt_d, bc_d, n_sweep = sw
+                n_fused = sum(n for _, n in fused.values())
+                if t.get("parts2") is None or t["parts2"].numel() < n_sweep + n_fused:
+                    t["parts2"] = torch.empty(n_sweep + n_fused, dtype=torch.float32, device=t["bt"].device)
+                parts, n_parts = t["parts2"], n_sweep + n_fused
+                torch.cat([sink.buf[o:o + n] for o, n in (fused[i] for i in key)], out=parts[n_sweep:n_parts])
+            if n_sweep > 0:
+                K.check(lib.otter_grad_sumsq(t["dmeta"].data_ptr(), bt_d.data_ptr(), bc_d.data_ptr(), n_sweep, parts.data_ptr(), stm), "grad_sumsq")
+            K.check(lib.otter_clip_coef(parts.data_ptr(), n_parts, float(self.max_grad_norm), t["norm"].data_ptr(), stm), "clip_coef")
             scale = t["norm"].data_ptr() + 4
             self.last_norm = t["norm"]
         # launch-wide lr / bias corrections are placeholders: every table row carries its own (bc1 != 0)

@@ -351,6 +351,16 @@ class TrainStep:
         self.grid_mode = _K.GRID_DEFAULT
         if self.reducer is not None and self.reducer.overlap and dev.type == "cuda" and os.environ.get("OTTER_DP_PERSISTENT") != "1":
             self.grid_mode = _K.GRID_PER_TILE
+        # Single rank + HIP optimizer + clipping: the large weight-gradient GEMMs also write sum(dW^2) per tile and the optimizer's norm sweep
+        # skips those tensors (functional.GradNormSink, round 6b).  With a reducer the norm is that of the AVERAGED gradient: not fusable.
+        # OTTER_NO_FUSED_GRAD_NORM=1: the plain sweep over every gradient (A/B switch).
+        self.norm_sink = None
+        if (self.hip_optimizer and self.reducer is None and max_grad_norm is not None and dev.type == "cuda"
+                and os.environ.get("OTTER_NO_FUSED_GRAD_NORM") != "1"):
+            from .functional import GradNormSink
+
+            self.norm_sink = GradNormSink()
+            self.optimizer.norm_sink = self.norm_sink
 
     def close(self):
         """Detach the DP reducer's autograd hooks and gradient sink (idempotent).  Call before building another TrainStep /
@@ -389,6 +399,9 @@ class TrainStep:
             sink.pending.clear()      # rows of a step that raised half-way through its backward must not leak into this one
             sink._expect, sink._nmax = 0, None
         _F.embed_sink = sink          # only while THIS step's graph is built and differentiated: plain autograd users never see it
+        if self.norm_sink is not None:
+            self.norm_sink.begin()
+        _F.norm_sink = self.norm_sink
         # the rows of every rank travel after the reduction only in this case (see below): their count is exchanged BEFORE backward
         rows_cross_ranks = (sink is not None and self.reducer is not None and self.reducer.sync and not self.masked_embeddings
                             and (self.world > 1 or self.reducer.force))
@@ -410,6 +423,7 @@ class TrainStep:
             raise
         finally:
             _F.embed_sink = None
+            _F.norm_sink = None
             scope.__exit__(None, None, None)
         if sink is not None and (self.masked_embeddings or self.reducer is None or not self.reducer.sync):
             sink.apply()                          # local: the mask below / the local accumulation needs the complete local gradient

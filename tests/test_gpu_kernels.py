@@ -617,6 +617,50 @@ def test_gemm_kmajor_operands(ops, M, N, Kd, ta, tb, pad):
         assert relmax(host(x3), host(want3)) < 1e-2 and relmax(host(x3), host(ops.sqrelu_bwd(aux, plain.to(torch.bfloat16)))) < 2e-2
 
 
+@pytest.mark.parametrize("M,N,Kd,km", [(4096, 16384, 512, True),     # the FFN weight-gradient launch: both operands K-major, 1024 tiles (variant 26)
+                                        (4104, 12304, 256, True),     # ragged edge tiles of the same kernel
+                                        (4096, 16384, 256, False),    # K-contiguous operands: the cross-tile form's tail
+                                        (1024, 512, 512, False),      # ring kernel (128 x 128 tiles; half-height tiles are not taken with partials)
+                                        (200, 136, 64, False)])       # generic kernel, partial tiles
+def test_gemm_store_sum_of_squares_partials(ops, M, N, Kd, km):
+    """Round 6b: a plain-store launch with an fp32 C also writes sum(C^2) per output tile (otter_epilogue_args::partial) -- the
+    clip_grad_norm_ reduction of a weight gradient taken in the launch that produces it.  Against the stored C itself in fp64, with the
+    gate scale and in the accumulate form (the sum is of the values as STORED); the stored C is bit-identical to the launch without
+    partials; bf16 outputs refuse partials."""
+    from otter_amd._capi import EPI_STORE, OtterHipError
+
+    r = rng(M + N + Kd)
+    A = to_dev(bf16_round(r.standard_normal((M, Kd)).astype(np.float32) * 0.5), torch.bfloat16)
+    B = to_dev(bf16_round(r.standard_normal((N, Kd)).astype(np.float32) * 0.5), torch.bfloat16)
+    if km:
+        A, B = A.t().contiguous(), B.t().contiguous()
+        assert ops.gemm_kmajor_supported(M, N, Kd, A.stride(0), B.stride(0), True, True, torch.bfloat16)
+    n = ops.gemm_num_partials(M, N, torch.bfloat16)
+    gate = to_dev(np.array([0.4], np.float32))
+
+    def launch(**kw):
+        return ops.gemm(A, B, km, km, out_dtype=torch.float32, kind=EPI_STORE, **kw) if km else ops.gemm_nt(A, B, out_dtype=torch.float32, kind=EPI_STORE, **kw)
+
+    for g in (None, gate):
+        part = torch.full((n,), float("nan"), dtype=torch.float32, device=DEV)
+        C = launch(gate=g, partial=part)
+        assert torch.equal(C, launch(gate=g))
+        want = float((C.double() ** 2).sum())
+        got = float(part.double().sum())
+        assert np.isfinite(got) and abs(got - want) <= 2e-6 * want, (got, want)
+    # accumulate: the partials are those of the sum
+    part = torch.full((n,), float("nan"), dtype=torch.float32, device=DEV)
+    C2 = launch()
+    if km:
+        ops.gemm(A, B, True, True, out=C2, kind=EPI_STORE, accumulate=True, partial=part)
+    else:
+        ops.gemm_nt(A, B, out=C2, kind=EPI_STORE, accumulate=True, partial=part)
+    want = float((C2.double() ** 2).sum())
+    assert abs(float(part.double().sum()) - want) <= 2e-6 * want
+    with pytest.raises(OtterHipError):
+        (ops.gemm(A, B, True, True, partial=part) if km else ops.gemm_nt(A, B, partial=part))
+
+
 def test_gemm_kmajor_any_reduction_length(ops):
     """Both operands K-major: K is a row count -- odd values included (rows past K lie outside both descriptors and read as zeros)."""
     r = rng(5)

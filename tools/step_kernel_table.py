@@ -10,7 +10,9 @@ f = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
 ad = [i for i, e in enumerate(ev) if "adamw_stream_kernel" in e[2]]
-lo, hi = ad[-4] + 1, ad[-1] + 1
+# warm-up 2 + 4 timed steps, then bench.py's calibration extras (one more step, the stand-alone block, the MFMA probe):
+# the window is the timed steps 1-3, counted from the front
+lo, hi = ad[2] + 1, ad[5] + 1
 win = ev[lo:hi]
 span = (win[-1][1] - win[0][0]) / 3e6
 tot, cnt = collections.Counter(), collections.Counter()
