@@ -515,30 +515,33 @@ class FrozenMLPFusedLegsFn(torch.autograd.Function):
     library + gelu_bwd 419.7; the plain products are 2-7 % faster on the library."""
 
     @staticmethod
-    def forward(ctx, x2, Wu, Wd, Wu_t):
+    def forward(ctx, x2, Wu, Wd, Wu_t, Wd_t=None):
         need = ctx.needs_input_grad[0]
         u = torch.empty((x2.shape[0], Wu.shape[0]), dtype=x2.dtype, device=x2.device) if need else None
         h = ops.gemm_nt(x2, Wu, kind=EPI_GELU, C2=u)
         y = torch.nn.functional.linear(h, Wd)
         if need:
-            ctx.save_for_backward(u, Wd, Wu_t)
+            ctx.have_wdt = Wd_t is not None
+            ctx.save_for_backward(u, Wd_t if Wd_t is not None else Wd, Wu_t)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         u, Wd, Wu_t = ctx.saved_tensors
         dy = dy.contiguous() if dy.dtype == u.dtype else dy.to(u.dtype).contiguous()
-        if ops.gemm_kmajor_supported(dy.shape[0], Wd.shape[1], Wd.shape[0], dy.stride(0), Wd.stride(0), False, True, dy.dtype):
+        if ctx.have_wdt:   # Wd here is the stored transposed copy [in, out]: both operands K-contiguous (the cross-tile form of variant 26)
+            du = ops.gemm_nt(dy, Wd, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+        elif ops.gemm_kmajor_supported(dy.shape[0], Wd.shape[1], Wd.shape[0], dy.stride(0), Wd.stride(0), False, True, dy.dtype):
             du = ops.gemm(dy, Wd, False, True, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
         else:
             du = ops.gemm_nt(dy, ops.transpose(Wd, Wd.dtype), kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
-        return torch.nn.functional.linear(du, Wu_t), None, None, None
+        return torch.nn.functional.linear(du, Wu_t), None, None, None, None
 
 
-def frozen_mlp_fused_legs(x, Wu, Wd, Wu_t):
+def frozen_mlp_fused_legs(x, Wu, Wd, Wu_t, Wd_t=None):
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
-    return FrozenMLPFusedLegsFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), Wu, Wd, Wu_t).view(shp[:-1] + (Wd.shape[0],))
+    return FrozenMLPFusedLegsFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), Wu, Wd, Wu_t, Wd_t).view(shp[:-1] + (Wd.shape[0],))
 
 
 def frozen_mlp(x, Wu, Wd):

@@ -208,6 +208,12 @@ class MPTMLP(nn.Module):
                 and not up.weight.requires_grad and not dn.weight.requires_grad and OF.compute_dtype_for(x) == torch.bfloat16):
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
             wu, wu_t = up._copies(torch.bfloat16)
+            # round 6b: the GELU' leg reads a stored transposed copy of the frozen down_proj (both operands K-contiguous: the cross-tile form of
+            # variant 26) instead of the weight as stored through the K-major form: 127.90 vs 128.33 ms per step on one box, 3 x 2 interleaved runs
+            # (profiles/r06b_mlp_dgrad_kcontig_ab.txt); 4.3 GB of copies for MPT-7B.  OTTER_MLP_DGRAD_KCONTIG=0: the K-major form (A/B switch).
+            if os.environ.get("OTTER_MLP_DGRAD_KCONTIG") != "0":
+                wd, wd_t = dn._copies(torch.bfloat16)
+                return OF.frozen_mlp_fused_legs(xb, wu, wd, wu_t, wd_t)
             return OF.frozen_mlp_fused_legs(xb, wu, dn._copy_w(torch.bfloat16), wu_t)
         u = self.up_proj(x)
         if u.is_cuda and os.environ.get("OTTER_TORCH_GELU") != "1":
