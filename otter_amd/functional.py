@@ -482,13 +482,17 @@ class FrozenMLPFn(torch.autograd.Function):
     weights: there is no weight gradient, so h is not kept.  x2 [rows, D], weights in the compute dtype (bf16)."""
 
     @staticmethod
-    def forward(ctx, x2, Wu, Wd):
+    def forward(ctx, x2, Wu, Wd, Wu_t=None, Wd_t=None):
         need = ctx.needs_input_grad[0]
         u = torch.empty((x2.shape[0], Wu.shape[0]), dtype=x2.dtype, device=x2.device) if need else None
         h = ops.gemm_nt(x2, Wu, kind=EPI_GELU, C2=u)
         y = ops.gemm_nt(h, Wd)
         if need:
-            ctx.save_for_backward(u, Wu, Wd)
+            ctx.have_t = Wu_t is not None and Wd_t is not None
+            if ctx.have_t:
+                ctx.save_for_backward(u, Wu_t, Wd_t)
+            else:
+                ctx.save_for_backward(u, Wu, Wd)
         return y
 
     @staticmethod
@@ -496,6 +500,9 @@ class FrozenMLPFn(torch.autograd.Function):
         u, Wu, Wd = ctx.saved_tensors
         dy = dy.contiguous() if dy.dtype == u.dtype else dy.to(u.dtype).contiguous()
         rows = dy.shape[0]
+        if ctx.have_t:   # stored transposed copies (mode "1t"): every operand K-contiguous
+            du = ops.gemm_nt(dy, Wd, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+            return ops.gemm_nt(du, Wu), None, None, None, None
         if ops.gemm_kmajor_supported(rows, Wd.shape[1], Wd.shape[0], dy.stride(0), Wd.stride(0), False, True, dy.dtype):
             du = ops.gemm(dy, Wd, False, True, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
         else:
@@ -504,7 +511,7 @@ class FrozenMLPFn(torch.autograd.Function):
             dx = ops.gemm(du, Wu, False, True)
         else:
             dx = ops.gemm_nt(du, ops.transpose(Wu, Wu.dtype))
-        return dx, None, None
+        return dx, None, None, None, None
 
 
 class FrozenMLPFusedLegsFn(torch.autograd.Function):
@@ -544,33 +551,36 @@ def frozen_mlp_fused_legs(x, Wu, Wd, Wu_t, Wd_t=None):
     return FrozenMLPFusedLegsFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), Wu, Wd, Wu_t, Wd_t).view(shp[:-1] + (Wd.shape[0],))
 
 
-def frozen_mlp(x, Wu, Wd):
+def frozen_mlp(x, Wu, Wd, Wu_t=None, Wd_t=None):
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
-    return FrozenMLPFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), Wu, Wd).view(shp[:-1] + (Wd.shape[0],))
+    return FrozenMLPFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), Wu, Wd, Wu_t, Wd_t).view(shp[:-1] + (Wd.shape[0],))
 
 
 class FrozenLinearOwnFn(torch.autograd.Function):
     """y = x W^T for a frozen bias-free Linear on csrc/gemm.hip; dx = dy W reads W as stored (K-major B operand)."""
 
     @staticmethod
-    def forward(ctx, x2, W):
-        ctx.save_for_backward(W)
+    def forward(ctx, x2, W, Wt=None):
+        ctx.have_t = Wt is not None
+        ctx.save_for_backward(Wt if Wt is not None else W)
         return ops.gemm_nt(x2, W)
 
     @staticmethod
     def backward(ctx, dy):
         (W,) = ctx.saved_tensors
         dy = dy.contiguous() if dy.dtype == W.dtype else dy.to(W.dtype).contiguous()
+        if ctx.have_t:   # stored transposed copy (mode "1t")
+            return ops.gemm_nt(dy, W), None, None
         if ops.gemm_kmajor_supported(dy.shape[0], W.shape[1], W.shape[0], dy.stride(0), W.stride(0), False, True, dy.dtype):
-            return ops.gemm(dy, W, False, True), None
-        return ops.gemm_nt(dy, ops.transpose(W, W.dtype)), None
+            return ops.gemm(dy, W, False, True), None, None
+        return ops.gemm_nt(dy, ops.transpose(W, W.dtype)), None, None
 
 
-def frozen_linear_own(x, W):
+def frozen_linear_own(x, W, Wt=None):
     shp = x.shape
     x2 = x.reshape(-1, shp[-1])
-    return FrozenLinearOwnFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), W).view(shp[:-1] + (W.shape[0],))
+    return FrozenLinearOwnFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), W, Wt).view(shp[:-1] + (W.shape[0],))
 
 
 class SwiGLUFn(torch.autograd.Function):

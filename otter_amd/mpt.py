@@ -115,11 +115,17 @@ def _own_mode() -> str:
             kernel: no transposed copies, 13 GB less): +1.2 % on the step (round 5: +4.0 %) -- the library's plain products are still ahead in situ.
       "0" / "lib": hipBLASLt for all of them + stand-alone GELU kernels (the round 1-5 default; A/B switch)."""
     v = os.environ.get("OTTER_OWN_DECODER_GEMM", "mlp").lower()
-    return {"1": "all", "mlp": "mlp", "": "mlp"}.get(v, "lib")
+    return {"1": "all", "1t": "allt", "mlp": "mlp", "": "mlp"}.get(v, "lib")
 
 
 def _own_gemm() -> bool:
-    return _own_mode() == "all"
+    return _own_mode() in ("all", "allt")
+
+
+def _own_transposed() -> bool:
+    """ "1t" (round 6b): as "1", but the input gradients read stored transposed copies of the frozen weights (K-contiguous operands, the
+    cross-tile form of variant 26) instead of the weights as stored through the K-major form -- the copies the library path keeps anyway."""
+    return _own_mode() == "allt"
 
 
 def _own_mlp_fused_legs() -> bool:
@@ -186,6 +192,9 @@ class FrozenAwareLinear(nn.Linear):
             return F.linear(x, w, self.bias)
         cd = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
         if _own_gemm() and cd == torch.bfloat16:
+            if _own_transposed():
+                wc, wt = self._copies(cd)
+                return OF.frozen_linear_own(x if x.dtype == cd else x.to(cd), wc, wt)
             return OF.frozen_linear_own(x if x.dtype == cd else x.to(cd), self._copy_w(cd))
         wc, wt = self._copies(cd)
         return _FrozenLinearFn.apply(x if x.dtype == cd else x.to(cd), wc, wt)
@@ -203,6 +212,9 @@ class MPTMLP(nn.Module):
         if (_own_gemm() and x.is_cuda and up.bias is None and dn.bias is None and not up.weight.requires_grad and not dn.weight.requires_grad
                 and OF.compute_dtype_for(x) == torch.bfloat16):
             xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+            if _own_transposed():
+                (wu, wu_t), (wd, wd_t) = up._copies(torch.bfloat16), dn._copies(torch.bfloat16)
+                return OF.frozen_mlp(xb, wu, wd, wu_t, wd_t)
             return OF.frozen_mlp(xb, up._copy_w(torch.bfloat16), dn._copy_w(torch.bfloat16))
         if (_own_mlp_fused_legs() and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and up.bias is None and dn.bias is None
                 and not up.weight.requires_grad and not dn.weight.requires_grad and OF.compute_dtype_for(x) == torch.bfloat16):
