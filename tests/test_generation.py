@@ -101,7 +101,15 @@ def test_unsupported_arguments_are_loud(pair):
     _, _, mine = pair
     ids = torch.ones(1, 3, dtype=torch.long)
     with pytest.raises(NotImplementedError):
-        generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beam_groups=2, diversity_penalty=0.5)
+        generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beams=2, force_words_ids=[[5]])
+    with pytest.raises(NotImplementedError):
+        generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, penalty_alpha=0.6, top_k=4)
+    with pytest.raises(ValueError):      # GenerationConfig.validate's rules of the group mode
+        generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beams=3, num_beam_groups=2, diversity_penalty=0.5)
+    with pytest.raises(ValueError):
+        generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beams=4, num_beam_groups=2)
+    with pytest.raises(ValueError):
+        generate_tokens(_step_for(mine, False), ids, None, max_new_tokens=2, num_beams=4, num_beam_groups=2, diversity_penalty=0.5, do_sample=True)
 
 
 def test_beam_sample_properties(pair):
@@ -176,3 +184,94 @@ def test_llama_use_cache_follows_config(pair):
     finally:
         mine.eval()
     mine.release_fused_copies()      # idempotent on a model that never built any
+
+
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_prefix_allowed_tokens_fn_matches_transformers(pair, use_cache):
+    """PrefixConstrainedLogitsProcessor (the installed transformers still carries it): greedy and beam search under a per-sentence rule."""
+    from otter_amd.generation import generate_tokens
+
+    cfg, ref, mine = pair
+    ids = torch.randint(3, cfg.vocab_size, (3, 5), generator=torch.Generator().manual_seed(31))
+    mask = torch.ones_like(ids)
+
+    def allowed(sentence, sofar):
+        last = int(sofar[-1])
+        return [v for v in range(2, cfg.vocab_size) if (v + last + sentence) % 3 != 0] + [1]
+
+    for kw in (dict(num_beams=1, max_new_tokens=9), dict(num_beams=3, max_new_tokens=9, no_repeat_ngram_size=3)):
+        with torch.no_grad():
+            want = ref.generate(input_ids=ids, attention_mask=mask, eos_token_id=1, pad_token_id=0, do_sample=False, prefix_allowed_tokens_fn=allowed, **kw)
+            got = generate_tokens(_step_for(mine, use_cache), ids, mask, eos_token_id=1, pad_token_id=0, prefix_allowed_tokens_fn=allowed, **kw)
+        # (the installed transformers leaves eos instead of pad behind a finished hypothesis when this processor is on -- its running beams go
+        #  on under the rule; 4.35.1's scorer pads: compare up to the first eos, and require padding behind it)
+        assert got.shape == want.shape
+        for r in range(got.shape[0]):
+            g_, w_ = got[r, 5:].tolist(), want[r, 5:].tolist()
+            n = g_.index(1) + 1 if 1 in g_ else len(g_)
+            assert g_[:n] == w_[:n] and all(t == 0 for t in g_[n:]), (kw, r, g_, w_)
+        new = got[:, 5:].tolist()
+        for r, row in enumerate(new):
+            prev = int(ids[r, -1])
+            for t in row:
+                if t == 0:
+                    break
+                assert t == 1 or (t + prev + r) % 3 != 0
+                prev = t
+
+
+def test_group_beam_search_with_identical_groups_is_beam_search(pair):
+    """Diverse beam search (transformers 4.35.1 group_beam_search; removed from the installed transformers, so pinned through its defining
+    properties): with the penalty at zero every group is an independent beam search of nb / ng beams over the same scores -- the best
+    hypothesis is the one `num_beams = nb / ng` finds, and the groups return the same hypotheses."""
+    from otter_amd.generation import generate_tokens
+
+    cfg, _, mine = pair
+    ids = torch.randint(3, cfg.vocab_size, (3, 6), generator=torch.Generator().manual_seed(41))
+    mask = torch.ones_like(ids)
+    common = dict(eos_token_id=1, pad_token_id=0, max_new_tokens=11, no_repeat_ngram_size=3, length_penalty=0.8)
+    for use_cache in (False, True):
+        plain = generate_tokens(_step_for(mine, use_cache), ids, mask, num_beams=2, num_return_sequences=2, **common)
+        grp = generate_tokens(_step_for(mine, use_cache), ids, mask, num_beams=6, num_beam_groups=3, diversity_penalty=0.0,
+                              _identical_groups_ok=True, num_return_sequences=6, **common)
+        L = max(plain.shape[1], grp.shape[1])
+        pad = lambda t: torch.nn.functional.pad(t, (0, L - t.shape[1]))
+        plain, grp = pad(plain), pad(grp)
+        for b in range(3):
+            mine_rows = {tuple(r.tolist()) for r in grp[6 * b: 6 * b + 6]}
+            assert mine_rows == {tuple(r.tolist()) for r in plain[2 * b: 2 * b + 2]}, (b, grp[6 * b: 6 * b + 6].tolist(), plain[2 * b: 2 * b + 2].tolist())
+            assert torch.equal(grp[6 * b], plain[2 * b])          # best first
+
+
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_group_beam_search_hamming_diversity_against_a_direct_restatement(pair, use_cache):
+    """With one beam per group the algorithm is a chain of greedy decoders, group g choosing argmax(log p - penalty x [how many of the groups
+    before it took that token at this step]); the scores it accumulates include the penalty (the processed scores are what the beam scorer
+    adds up).  Restated here directly on the host model and compared token for token, hypothesis order included."""
+    from otter_amd.generation import generate_tokens
+
+    cfg, _, mine = pair
+    ng, new, pen = 4, 8, 1.7
+    ids = torch.randint(3, cfg.vocab_size, (2, 5), generator=torch.Generator().manual_seed(43))
+    got = generate_tokens(_step_for(mine, use_cache), ids, torch.ones_like(ids), eos_token_id=None, pad_token_id=0, max_new_tokens=new,
+                          num_beams=ng, num_beam_groups=ng, diversity_penalty=pen, num_return_sequences=ng, length_penalty=1.0)
+    assert got.shape == (2 * ng, 5 + new)
+    for b in range(2):
+        seqs = [ids[b].clone() for _ in range(ng)]
+        tot = [0.0] * ng
+        for _ in range(new):
+            taken = []
+            for g in range(ng):
+                with torch.no_grad():
+                    lp = torch.log_softmax(mine(input_ids=seqs[g][None]).logits[0, -1].float(), -1)
+                for t in taken:
+                    lp[t] -= pen
+                t = int(lp.argmax())
+                tot[g] += float(lp[t])
+                taken.append(t)
+                seqs[g] = torch.cat([seqs[g], torch.tensor([t])])
+        order = sorted(range(ng), key=lambda g: -tot[g] / new)
+        want = torch.stack([seqs[g] for g in order])
+        assert torch.equal(got[ng * b: ng * b + ng], want), (b, got[ng * b: ng * b + ng].tolist(), want.tolist(), tot)
+        first = [int(s[5]) for s in seqs]
+        assert len(set(first)) > 1        # the penalty did push groups apart
