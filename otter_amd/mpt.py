@@ -115,7 +115,7 @@ def _own_mode() -> str:
             kernel: no transposed copies, 13 GB less): +1.2 % on the step (round 5: +4.0 %) -- the library's plain products are still ahead in situ.
       "0" / "lib": hipBLASLt for all of them + stand-alone GELU kernels (the round 1-5 default; A/B switch)."""
     v = os.environ.get("OTTER_OWN_DECODER_GEMM", "mlp").lower()
-    return {"1": "all", "1t": "allt", "mlp": "mlp", "": "mlp"}.get(v, "lib")
+    return {"1": "all", "1t": "allt", "mlp": "mlp", "": "mlp", "attn": "attn", "attn_qkv": "attn_qkv", "attn_out": "attn_out"}.get(v, "lib")
 
 
 def _own_gemm() -> bool:
@@ -129,7 +129,20 @@ def _own_transposed() -> bool:
 
 
 def _own_mlp_fused_legs() -> bool:
-    return _own_mode() == "mlp"
+    return _own_mode() in ("mlp", "attn", "attn_qkv", "attn_out")
+
+
+def _own_attn_linear(out_features: int, in_features: int) -> bool:
+    """ "attn" / "attn_qkv" / "attn_out" (round 6c, A/B switches): the default "mlp" mode PLUS the attention projections (Wqkv and / or
+    out_proj, forward and input gradient) on csrc/gemm.hip against stored transposed copies -- which of the plain products the library wins."""
+    m = _own_mode()
+    if m == "attn":
+        return True
+    if m == "attn_qkv":
+        return out_features == 3 * in_features
+    if m == "attn_out":
+        return out_features == in_features
+    return False
 
 
 def _lin(x, w):
@@ -196,6 +209,9 @@ class FrozenAwareLinear(nn.Linear):
                 wc, wt = self._copies(cd)
                 return OF.frozen_linear_own(x if x.dtype == cd else x.to(cd), wc, wt)
             return OF.frozen_linear_own(x if x.dtype == cd else x.to(cd), self._copy_w(cd))
+        if cd == torch.bfloat16 and _own_attn_linear(self.out_features, self.in_features):
+            wc, wt = self._copies(cd)
+            return OF.frozen_linear_own(x if x.dtype == cd else x.to(cd), wc, wt)
         wc, wt = self._copies(cd)
         return _FrozenLinearFn.apply(x if x.dtype == cd else x.to(cd), wc, wt)
 
