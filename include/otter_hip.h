@@ -112,11 +112,14 @@ int otter_rmsnorm_bwd_ex(const void* dy, int dy_dtype, const void* x, int x_dtyp
  *                       clip_grad_norm_ reduction of a weight gradient (pipeline/train/instruction_following.py:246-247) taken in the
  *                       producing launch instead of by a second sweep over the tensor; summed by otter_clip_coef like any other partial.
  *   OTTER_EPI_GELU      C = gelu_erf(acc); C2 = acc       (Linear -> nn.GELU, :366-367 / :145-146; C2 optional)
+ *                       with aux_is_gelu_input == 3 (round 6c): C2 = gelu_erf'(acc) -- the DERIVATIVE is stashed for a backward that needs
+ *                       nothing else of the pre-activation (a frozen MLP: mpt/blocks.py:9-20), see OTTER_EPI_GATE_BWD
  *   OTTER_EPI_SCALE_RES C = acc * s + R                  (x = attn(...) * attn_gate.tanh() + x, :380-393;
  *                                                          gate == NULL gives the perceiver's plain residual :180,184)
  *   OTTER_EPI_GATE_BWD  C = s * acc * f'(aux);  partial[block] = sum(acc * f(aux))
  *                       f = identity (aux_is_gelu_input == 0), gelu_erf (1) or the squared ReLU relu(a)^2 of the Persimmon MLP
- *                       (2; /root/reference/src/otter_ai/models/fuyu/modeling_persimmon.py:180-194).
+ *                       (2; /root/reference/src/otter_ai/models/fuyu/modeling_persimmon.py:180-194); 3: aux already holds f'(a)
+ *                       (stashed by the forward launch): C = s * acc * aux, partial must be NULL.
  *                       This is the dgrad GEMM of a gated branch: it yields d(branch input) and, through the
  *                       deterministic two-stage reduction otter_reduce_partials, the gradient of the scalar gate.
  * A/B are both ab_dtype.  bf16 operands run on MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate); f32 operands
@@ -136,7 +139,7 @@ typedef struct {
     const void* aux;     /* GATE_BWD */
     int64_t ldaux;
     int aux_dtype;
-    int aux_is_gelu_input; /* 0 identity, 1 erf GELU, 2 squared ReLU */
+    int aux_is_gelu_input; /* 0 identity, 1 erf GELU, 2 squared ReLU, 3 stashed derivative (GELU launch: C2 = GELU'; GATE_BWD launch: aux = f') */
     float* partial;      /* GATE_BWD, STORE with an f32 C: [otter_gemm_num_partials(M,N)] floats, or NULL */
     int grid_mode;       /* otter_grid_mode of THIS launch (ABI 2): how the large-grid kernel maps tiles to workgroups */
 } otter_epilogue_args;

@@ -162,6 +162,29 @@ __device__ __forceinline__ void gelu_fast(const float (&v)[NE], float (&o)[NE]) 
         o[2 * p] = r.x; o[2 * p + 1] = r.y;
     }
 }
+// GELU(v) AND GELU'(v) of NE = 2 NP values (round 6c, the derivative-stash form of the frozen MLP: the forward tail writes h = GELU(u) and
+// g = GELU'(u) = Phi(u) + u phi(u) instead of u; the backward tail then only multiplies): the polynomial Phi + one v_exp_f32 per element
+template <int NE>
+__device__ __forceinline__ void gelu_and_grad_fast(const float (&v)[NE], float (&o)[NE], float (&gp)[NE]) {
+    constexpr int NP = NE / 2;
+    otter_f2 u[NP], cdf[NP], e[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) u[p] = otter_f2{v[2 * p], v[2 * p + 1]};
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const otter_f2 arg = (u[p] * u[p]) * -0.72134752044448170368f;   // exp(-u^2 / 2) = exp2(-u^2 / (2 ln 2))
+        e[p].x = __builtin_amdgcn_exp2f(arg.x);
+        e[p].y = __builtin_amdgcn_exp2f(arg.y);
+    }
+    gelu_cdf_fast<NP>(u, cdf);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const otter_f2 r = u[p] * cdf[p];
+        const otter_f2 g = (u[p] * e[p]) * 0.39894228040143267794f + cdf[p];
+        o[2 * p] = r.x; o[2 * p + 1] = r.y;
+        gp[2 * p] = g.x; gp[2 * p + 1] = g.y;
+    }
+}
 // gate / GELU backward of NE values: o = s v GELU'(a) with GELU'(a) = Phi(a) + a phi(a) (the polynomial Phi + ONE v_exp_f32 per element for
 // the density), returns sum v GELU(a)
 template <int NE>

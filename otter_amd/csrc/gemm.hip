@@ -105,6 +105,21 @@ __device__ __forceinline__ void gelu_apply(bool fast, const float (&v)[NE], floa
         }
     }
 }
+// GELU forward whose second output is the DERIVATIVE (otter_epilogue_args::aux_is_gelu_input == 3 on an OTTER_EPI_GELU launch)
+template <int NE>
+__device__ __forceinline__ void gelu_apply_stash(bool fast, const float (&v)[NE], float (&o)[NE], float (&gp)[NE]) {
+    if (fast) {
+        gelu_and_grad_fast<NE>(v, o, gp);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            float cdf, pdf;
+            gelu_cdf_pdf(v[i], cdf, pdf);
+            o[i] = v[i] * cdf;
+            gp[i] = cdf + v[i] * pdf;
+        }
+    }
+}
 template <int NE>
 __device__ __forceinline__ float gelu_bwd_apply(bool fast, float s, const float (&v)[NE], const float (&a)[NE], float (&o)[NE]) {
     float part = 0.f;
@@ -153,8 +168,14 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
             break;
         }
         case OTTER_EPI_GELU: {
-            if (g.C2) store4(g.C2, m * g.ldc2 + n, g.cdt, v);
-            gelu_apply<4>(g.cdt == OTTER_BF16, v, o);   // bf16 results: the packed polynomial, as in the full-tile tails (tail_apply)
+            if (g.C2 && g.aux_gelu == 3) {   // derivative stash: C2 = GELU'(acc)
+                float gp[4];
+                gelu_apply_stash<4>(g.cdt == OTTER_BF16, v, o, gp);
+                store4(g.C2, m * g.ldc2 + n, g.cdt, gp);
+            } else {
+                if (g.C2) store4(g.C2, m * g.ldc2 + n, g.cdt, v);
+                gelu_apply<4>(g.cdt == OTTER_BF16, v, o);   // bf16 results: the packed polynomial, as in the full-tile tails (tail_apply)
+            }
             store4(g.C, m * g.ldc + n, g.cdt, o);
             break;
         }
@@ -169,7 +190,10 @@ __device__ __forceinline__ float epilogue4(const GemmArgs& g, float s, int64_t m
         default: {  // OTTER_EPI_GATE_BWD
             float a[4];
             load4(g.aux, m * g.ldaux + n, g.auxdt, a);
-            if (g.aux_gelu == 2) {   // squared ReLU (Persimmon MLP): f(a) = relu(a)^2, f'(a) = 2 relu(a)
+            if (g.aux_gelu == 3) {   // aux IS the stashed derivative f'(a): no activation arithmetic, no gate partial
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = s * v[i] * a[i];
+            } else if (g.aux_gelu == 2) {   // squared ReLU (Persimmon MLP): f(a) = relu(a)^2, f'(a) = 2 relu(a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float r = fmaxf(a[i], 0.f);
@@ -235,8 +259,14 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m
             break;
         }
         case OTTER_EPI_GELU: {
-            if (g.C2) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
-            gelu_apply<8>(g.cdt == OTTER_BF16, v, o);   // bf16 results: the packed polynomial, as in the full-tile tails (tail_apply)
+            if (g.C2 && g.aux_gelu == 3) {
+                float gp[8];
+                gelu_apply_stash<8>(g.cdt == OTTER_BF16, v, o, gp);
+                store8w(g.C2, m * g.ldc2 + n, g.cdt, gp);
+            } else {
+                if (g.C2) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
+                gelu_apply<8>(g.cdt == OTTER_BF16, v, o);   // bf16 results: the packed polynomial, as in the full-tile tails (tail_apply)
+            }
             break;
         }
         case OTTER_EPI_SCALE_RES: {
@@ -249,7 +279,10 @@ __device__ __forceinline__ float epilogue8(const GemmArgs& g, float s, int64_t m
         default: {  // OTTER_EPI_GATE_BWD
             float a[8];
             load8w(g.aux, m * g.ldaux + n, g.auxdt, a);
-            if (g.aux_gelu == 2) {
+            if (g.aux_gelu == 3) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = s * v[i] * a[i];
+            } else if (g.aux_gelu == 2) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float r = fmaxf(a[i], 0.f);
@@ -416,18 +449,28 @@ __device__ __forceinline__ float tail_apply(const GemmArgs& g, float s, int64_t 
         }
         if (g.cdt == OTTER_F32) part = sumsq_of<NE>(o);   // (g.cdt is a compile-time constant in the full-tile tails: bf16 stores carry nothing extra)
     } else if constexpr (EPI == OTTER_EPI_GELU) {
-        if (g.C2) {
-            if constexpr (NE == 8) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
-            else store4(g.C2, m * g.ldc2 + n, g.cdt, v);
+        if (g.C2 && g.aux_gelu == 3) {   // derivative stash (round 6c): C2 = GELU'(acc) instead of acc
+            float gp[NE];
+            gelu_apply_stash<NE>(g.cdt == OTTER_BF16, v, o, gp);
+            if constexpr (NE == 8) store8w(g.C2, m * g.ldc2 + n, g.cdt, gp);
+            else store4(g.C2, m * g.ldc2 + n, g.cdt, gp);
+        } else {
+            if (g.C2) {
+                if constexpr (NE == 8) store8w(g.C2, m * g.ldc2 + n, g.cdt, v);
+                else store4(g.C2, m * g.ldc2 + n, g.cdt, v);
+            }
+            gelu_apply<NE>(g.cdt == OTTER_BF16, v, o);   // (the dtype is a compile-time constant in the full-tile tails)
         }
-        gelu_apply<NE>(g.cdt == OTTER_BF16, v, o);   // (the dtype is a compile-time constant in the full-tile tails)
     } else if constexpr (EPI == OTTER_EPI_SCALE_RES) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) o[i] = v[i] * s + a[i];
     } else {
         // the aux kind is tested ONCE, outside the element loop: inside it the compiler kept a scalar branch between
         // elements, which serialised eight independent rcp / exp / fma chains (gate-backward tail: 88 k cycles per tile)
-        if (g.aux_gelu == 2) {   // squared ReLU: f'(a) = 2 relu(a)
+        if (g.aux_gelu == 3) {   // aux is the stashed derivative (round 6c)
+#pragma unroll
+            for (int i = 0; i < NE; ++i) o[i] = s * v[i] * a[i];
+        } else if (g.aux_gelu == 2) {   // squared ReLU: f'(a) = 2 relu(a)
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const float r = fmaxf(a[i], 0.f);
@@ -2864,6 +2907,7 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
             break;
         case OTTER_EPI_GELU:
             OTTER_REQUIRE(!g.C2 || g.ldc2 % 4 == 0, "gemm: ldc2 %% 4");
+            OTTER_REQUIRE(g.aux_gelu == 0 || g.aux_gelu == 3, "gemm: a GELU launch takes aux_is_gelu_input 0 (C2 = pre-activation) or 3 (C2 = GELU'), got %d", g.aux_gelu);
             break;
         case OTTER_EPI_SCALE_RES:
             OTTER_REQUIRE(g.R && g.ldr % 4 == 0, "gemm: SCALE_RES needs R with ldr %% 4 == 0");
@@ -2871,7 +2915,8 @@ static int gemm_impl(const void* A, int64_t lda, int a_kmajor, const void* B, in
             break;
         case OTTER_EPI_GATE_BWD:
             OTTER_REQUIRE(g.aux && g.ldaux % 4 == 0, "gemm: GATE_BWD needs aux with ldaux %% 4 == 0");
-            OTTER_REQUIRE(g.aux_gelu >= 0 && g.aux_gelu <= 2, "gemm: aux activation %d (0 = identity, 1 = erf GELU, 2 = squared ReLU)", g.aux_gelu);
+            OTTER_REQUIRE(g.aux_gelu >= 0 && g.aux_gelu <= 3, "gemm: aux activation %d (0 = identity, 1 = erf GELU, 2 = squared ReLU, 3 = aux is the stashed derivative)", g.aux_gelu);
+            OTTER_REQUIRE(g.aux_gelu != 3 || !g.partial, "gemm: a stashed derivative (aux_is_gelu_input 3) cannot give the gate partial sum(acc * f(aux))");
             break;
         default:
             OTTER_FAIL(OTTER_ERR_ARG, "gemm: unknown epilogue %d", g.kind);

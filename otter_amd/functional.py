@@ -514,6 +514,11 @@ class FrozenMLPFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+def mlp_stash_dgelu() -> bool:
+    """OTTER_MLP_STASH_DGELU=1 (round 6c, opt-in A/B switch): the frozen MLP keeps GELU'(u) instead of u between forward and backward."""
+    return os.environ.get("OTTER_MLP_STASH_DGELU", "0") == "1"
+
+
 class FrozenMLPFusedLegsFn(torch.autograd.Function):
     """The frozen decoder MLP with ONLY its two fusable products on csrc/gemm.hip -- up_proj with GELU in the tail (u kept beside it) and
     down_proj's input gradient with GELU' in the tail, read against the weight as stored (K-major kernel: no transposed copy of down_proj) --
@@ -525,7 +530,10 @@ class FrozenMLPFusedLegsFn(torch.autograd.Function):
     def forward(ctx, x2, Wu, Wd, Wu_t, Wd_t=None):
         need = ctx.needs_input_grad[0]
         u = torch.empty((x2.shape[0], Wu.shape[0]), dtype=x2.dtype, device=x2.device) if need else None
-        h = ops.gemm_nt(x2, Wu, kind=EPI_GELU, C2=u)
+        # derivative stash (round 6c): with frozen weights the backward needs GELU'(u) and nothing else of u, so the forward tail -- bound by its
+        # two outputs' stores, with arithmetic to spare -- writes g = GELU'(u) in u's place and the backward tail only multiplies
+        ctx.stash = need and mlp_stash_dgelu()
+        h = ops.gemm_nt(x2, Wu, kind=EPI_GELU, C2=u, aux_gelu="stash" if ctx.stash else False)
         y = torch.nn.functional.linear(h, Wd)
         if need:
             ctx.have_wdt = Wd_t is not None
@@ -536,12 +544,13 @@ class FrozenMLPFusedLegsFn(torch.autograd.Function):
     def backward(ctx, dy):
         u, Wd, Wu_t = ctx.saved_tensors
         dy = dy.contiguous() if dy.dtype == u.dtype else dy.to(u.dtype).contiguous()
+        act = "stash" if ctx.stash else True
         if ctx.have_wdt:   # Wd here is the stored transposed copy [in, out]: both operands K-contiguous (the cross-tile form of variant 26)
-            du = ops.gemm_nt(dy, Wd, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+            du = ops.gemm_nt(dy, Wd, kind=EPI_GATE_BWD, aux=u, aux_gelu=act)
         elif ops.gemm_kmajor_supported(dy.shape[0], Wd.shape[1], Wd.shape[0], dy.stride(0), Wd.stride(0), False, True, dy.dtype):
-            du = ops.gemm(dy, Wd, False, True, kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+            du = ops.gemm(dy, Wd, False, True, kind=EPI_GATE_BWD, aux=u, aux_gelu=act)
         else:
-            du = ops.gemm_nt(dy, ops.transpose(Wd, Wd.dtype), kind=EPI_GATE_BWD, aux=u, aux_gelu=True)
+            du = ops.gemm_nt(dy, ops.transpose(Wd, Wd.dtype), kind=EPI_GATE_BWD, aux=u, aux_gelu=act)
         return torch.nn.functional.linear(du, Wu_t), None, None, None, None
 
 

@@ -215,7 +215,9 @@ def gemm_nt(A, B, out_dtype=None, out=None, kind=EPI_STORE, gate=None, R=None, C
     if aux is not None:
         aux = _c2d(aux)
         e.aux, e.ldaux, e.aux_dtype = aux.data_ptr(), aux.stride(0), K.dt(aux)
-    e.aux_is_gelu_input = 2 if aux_gelu == "sqrelu" else (1 if aux_gelu else 0)    # activation whose derivative the GATE_BWD tail applies to aux
+    # activation whose derivative the GATE_BWD tail applies to aux; "stash": the derivative itself travels (GELU launch: C2 = GELU'(acc),
+    # GATE_BWD launch: aux holds it)
+    e.aux_is_gelu_input = 3 if aux_gelu == "stash" else (2 if aux_gelu == "sqrelu" else (1 if aux_gelu else 0))
     e.partial = K.ptr(partial)
     e.grid_mode = _grid_mode
     if _GEMM_LOG is not None:

@@ -327,6 +327,50 @@ def test_gemm_epilogues(ops, dt, variant):
         ops.set_gemm_variant(0)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(300, 264, 256), (1024, 2048, 512), (4096, 16384, 256)])
+def test_gemm_gelu_derivative_stash(ops, dt, shape):
+    """Round 6c, otter_epilogue_args::aux_is_gelu_input == 3: a GELU launch writes C = GELU(acc) and C2 = GELU'(acc) (instead of acc), a
+    GATE_BWD launch whose aux holds that derivative only multiplies.  Every kernel family the shapes select (ring, large-grid incl. the
+    cross-tile form, edge tiles), fp32 and bf16 results; the pair composes to what the plain pair (C2 = acc, aux = acc with the GELU flag)
+    gives, within the rounding of the stashed value."""
+    from otter_amd._capi import EPI_GATE_BWD, EPI_GELU
+
+    M, N, Kd = shape
+    r = rng(601 + M)
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    A = r.standard_normal((M, Kd)).astype(np.float32) * 0.12
+    B = r.standard_normal((N, Kd)).astype(np.float32) * 0.12
+    if dt == "bf16":
+        A, B = bf16_round(A), bf16_round(B)
+    dA, dB = to_dev(A, tdt), to_dev(B, tdt)
+    acc = torch.from_numpy(A).double().to(DEV) @ torch.from_numpy(B).double().to(DEV).T
+    gelu = 0.5 * acc * (1 + torch.erf(acc * 0.5 ** 0.5))
+    grad = 0.5 * (1 + torch.erf(acc * 0.5 ** 0.5)) + acc * torch.exp(-0.5 * acc * acc) * (1.0 / (2 * np.pi) ** 0.5)
+    for odt in ([torch.float32] if dt == "f32" else [torch.float32, torch.bfloat16]):
+        tol = (3e-5 if dt == "f32" else 1e-4) if odt == torch.float32 else 6e-3
+        C2 = torch.empty((M, N), dtype=odt, device=DEV)
+        C = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GELU, C2=C2, aux_gelu="stash")
+        assert float((C.double() - gelu).abs().max()) < tol * float(gelu.abs().max()) + tol
+        assert float((C2.double() - grad).abs().max()) < tol * 1.13 + tol       # GELU' lies in [-0.13, 1.13]
+        # the plain pair on the same operands: same C bit for bit (the stash only changes what lands in C2)
+        U = torch.empty((M, N), dtype=odt, device=DEV)
+        Cp = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GELU, C2=U)
+        assert torch.equal(C, Cp)
+        # backward: a product times the stash, against the plain tail on the stored pre-activation
+        if odt == tdt:
+            dU_s = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GATE_BWD, aux=C2, aux_gelu="stash")
+            dU_p = ops.gemm_nt(dA, dB, out_dtype=odt, kind=EPI_GATE_BWD, aux=U, aux_gelu=True)
+            want = acc * grad
+            scale = float(want.abs().max())
+            e_s, e_p = float((dU_s.double() - want).abs().max()) / scale, float((dU_p.double() - want).abs().max()) / scale
+            assert e_s < (1e-4 if odt == torch.float32 else 1.2e-2), (e_s, e_p)
+            assert e_s < 2.0 * e_p + 1e-4, (e_s, e_p)          # not worse than the plain form beyond the one extra rounding
+    with pytest.raises(Exception):     # no gate partial from a stashed derivative
+        part = torch.zeros(ops.gemm_num_partials(M, N, tdt), dtype=torch.float32, device=DEV)
+        ops.gemm_nt(dA, dB, out_dtype=tdt, kind=EPI_GATE_BWD, aux=to_dev(np.zeros((M, N), np.float32), tdt), aux_gelu="stash", partial=part)
+
+
 @pytest.mark.parametrize("variant", variants(17, 18, 19, 20, 21, 22, 23, 25, 26, 30))
 @pytest.mark.parametrize("out_dt", ["bf16", "f32"])
 def test_gemm_full_tile_fast_tail(ops, variant, out_dt):
