@@ -31,6 +31,11 @@ thread_local char g_otter_err[512] = {0};
 // and the launch's shape + operand layout (mark 7: M in 20 bits, N, K in 21 bits each, bits 63 / 62 = A / B K-major).
 __device__ unsigned long long g_gemm_timeline[2 * 4 * 8 * 8];
 
+// tools-only ablation builds of variant 26's K loop (-DOTTER_T4_ABL=mask; build.build_gemm_define): 1 = no LDS-DMA inside the K loop, 2 = no fragment
+// reads, 4 = no workgroup barriers, 8 = no waits for the LDS-DMA, 16 = a piece's scalar instructions without its buffer_load.  Timing only -- the results are wrong by construction; the product build has mask 0.
+#ifndef OTTER_T4_ABL
+#define OTTER_T4_ABL 0
+#endif
 namespace {
 
 struct GemmArgs {
@@ -1494,7 +1499,11 @@ __device__ __forceinline__ void gemm_dma16_asm(u32x4_t r, unsigned lds, uint32_t
     // M0 is clobbered, not restored: nothing else in a K-major instantiation uses it (every LDS-DMA of the kernel is this statement), and
     // with one wave per SIMD every instruction beside an MFMA is an issue slot -- the save / restore / settle form of csrc/flash.hip
     // (6 instructions, > 16 cycles) stalled the matrix pipe at each of the 16 pieces of a K-tile (measured: 449 vs 379 us).
+#if (OTTER_T4_ABL & 16)   // ablation build: the scalar part of a piece only
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
     // (m0 cannot be named as a clobber -- it is a reserved register to hipcc, which never keeps a value in it across statements: every
     //  compiler-generated use is preceded by its own s_mov)
 }
@@ -1676,7 +1685,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #define LDF(dst, base_lo, base_hi, BUFV, KS, I)                                                                                     \
     do {                                                                                                                          \
-        if constexpr (base_lo##_T) {                                                                                              \
+        if constexpr ((OTTER_T4_ABL & 2) != 0) { /* ablation build: no fragment reads inside the K loop */ }                         \
+        else if constexpr (base_lo##_T) {                                                                                              \
             if constexpr ((I) == 0) asm volatile("" : "+v"(base_lo##_tb[(BUFV) & 1]));   /* opaque per use of block 0: no hoisting */   \
             dst = ldf_tr<(I)>(base_lo##_tb[(BUFV) & 1], (KS) * 16384);                                                              \
         }                                                                                                                         \
@@ -1715,6 +1725,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     // plain form: K-tiles walked from `krot_plain` on (g.korder bits 0-1, a function of the tile's index: see xt_tile) -- kt is the logical index
     int krot_plain = 0;
     auto dma = [&](int bufv, int kt, int p) {
+        if constexpr ((OTTER_T4_ABL & 1) != 0) { if (kt >= 2) return; }   // ablation build: no LDS-DMA inside the K loop (timing only, wrong results)
         const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
         if constexpr (!XT) {
             kt += krot_plain;
@@ -1903,6 +1914,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             if constexpr (TB) fn[0][i] = ldf_tr_rt(rb_tb[0], 0, i);
             else fn[0][i] = *reinterpret_cast<const bf16x8_t*>(smem + rb[0] + i * 2048);
         }
+        if constexpr ((OTTER_T4_ABL & 2) != 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { fm[1][i] = fm[0][i]; fn[1][i] = fn[0][i]; }
+        }
         TMARK(1);
 // K-major instantiations: asm MFMAs on explicit AGPR blocks (see AC_mi_ni above).  With the builtin, hipcc's register allocator gives up
 // on these variants (two 64-bit transpose reads per fragment instead of one 128-bit read): accumulators end up in VGPRs, every MFMA
@@ -1919,7 +1934,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 // iteration of a cross-tile tile (DMA == 2) -- N pieces plus the previous tile's tail, of which xt_slack operations may stay in flight
 #define T4_WAIT_NEXT(DMA, N)                                                                                              \
     do {                                                                                                                  \
-        if ((DMA) == 2) {                                                                                                 \
+        if constexpr ((OTTER_T4_ABL & 8) != 0) { /* ablation build: the K loop never waits for its LDS-DMA */ }           \
+        else if ((DMA) == 2) {                                                                                                 \
             if (xt_slack) asm volatile("s_waitcnt vmcnt(%c0)" : : "n"((N) + 32) : "memory");                              \
             else asm volatile("s_waitcnt vmcnt(%c0)" : : "n"(N) : "memory");                                              \
         } else if (DMA) asm volatile("s_waitcnt vmcnt(%c0)" : : "n"(N) : "memory");                                       \
@@ -1927,6 +1943,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     } while (0)
 // the 128-slot K-tile schedules (tools/gen/gemm_t4_schedule.py inc): KTILE_T0_0 (K-contiguous operands) / KTILE_X0_0 (K-major: split
 // transpose reads)
+#if (OTTER_T4_ABL & 4)   // ablation build: no workgroup barriers inside the K loop
+#define __builtin_amdgcn_s_barrier() ((void)0)
+#endif
 #include "gemm_t4_ktile.inc"
 #define KTILE_T0 KTILE_T0_0
 #define KTILE_X0 KTILE_X0_0
@@ -1984,6 +2003,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             else KLOOP_XT(KTILE_T0);
         } else if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP(KTILE_X0);
         else KLOOP(KTILE_T0);
+#endif
+#if (OTTER_T4_ABL & 4)
+#undef __builtin_amdgcn_s_barrier
 #endif
 #undef KLOOP
 #undef KLOOP_XT
