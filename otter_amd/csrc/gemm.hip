@@ -36,6 +36,10 @@ __device__ unsigned long long g_gemm_timeline[2 * 4 * 8 * 8];
 #ifndef OTTER_T4_ABL
 #define OTTER_T4_ABL 0
 #endif
+// cross-tile K-contiguous instantiations of variant 26: M0 written once per four LDS-DMA pieces (1 default; 0 = one s_mov per piece: the A/B build)
+#ifndef OTTER_T4_M0GROUP
+#define OTTER_T4_M0GROUP 1
+#endif
 namespace {
 
 struct GemmArgs {
@@ -1508,6 +1512,19 @@ __device__ __forceinline__ void gemm_dma16_asm(u32x4_t r, unsigned lds, uint32_t
     //  compiler-generated use is preceded by its own s_mov)
 }
 
+// Grouped form (round 6d, cross-tile K-contiguous instantiations): a wave's pieces of one operand are 1 KB apart in LDS, so M0 is written once per
+// FOUR pieces and pieces 1-3 of a group ride on the instruction's immediate offset (1024 q) -- which the hardware adds to the LDS address AND to the
+// global address: the per-lane source offset of piece q is stored 1024 q low.  tools/probe/dma_issue.hip: an `s_mov m0 + s_nop` pair beside
+// back-to-back MFMAs costs ~12 cycles of matrix pipe; 12 of the 16 pairs of a K-tile go (profiles/r06d_dma_issue_probe.txt: +6 % MFMA rate on zeros,
+// +3-4 % on random operands).  Nothing else in these kernels touches M0 (checked in the object code: 128 s_mov m0 = 128 LDS-DMA instructions).
+template <int Q>
+__device__ __forceinline__ void gemm_dma16_asm_q(u32x4_t r, unsigned lds_group, uint32_t voff_low, uint32_t soff) {
+    if constexpr (Q == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    else if constexpr (Q == 1) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    else if constexpr (Q == 2) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+}
+
 // Address of a transpose read: k-row, half row, swizzled block and the lane's 8 bytes occupy DISJOINT bit fields of the LDS
 // offset (bits 9-13 | 8 | 5-7 | 3-4; the +4 rows of the second read, the k-step, the operand region and the buffer are higher or
 // free bits), so  row*512 + half*256 + ((i ^ f) * 32) + 8 (r & 3)  ==  lane_const ^ (i * 32): ONE v_xor_b32 with a literal per
@@ -1724,12 +1741,25 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
     // plain form: K-tiles walked from `krot_plain` on (g.korder bits 0-1, a function of the tile's index: see xt_tile) -- kt is the logical index
     int krot_plain = 0;
+    constexpr bool M0G = XT && !TA && !TB && (OTTER_T4_M0GROUP != 0);   // M0 written once per four pieces (gemm_dma16_asm_q)
     auto dma = [&](int bufv, int kt, int p) {
         if constexpr ((OTTER_T4_ABL & 1) != 0) { if (kt >= 2) return; }   // ablation build: no LDS-DMA inside the K loop (timing only, wrong results)
         const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
         if constexpr (!XT) {
             kt += krot_plain;
             if (kt >= nk) kt -= nk;
+        }
+        if constexpr (XT && M0G) {   // grouped M0 (see gemm_dma16_asm_q): wave w fills the 1 KB chunks 8 w .. 8 w + 7 of each operand's 32 KB, piece by piece
+            const unsigned grp = smem_lds + (unsigned)((bufv & 1) * TILE + (p >> 3) * (BM * 128) + (wave * 8 + (p & 4)) * 1024);
+            const uint32_t vo = p < 8 ? oa[p & 7] : ob[p & 7];
+            const uint32_t so = p < 8 ? sa_k : sb_k;
+            switch (p & 3) {
+                case 0: if (p < 8) gemm_dma16_asm_q<0>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<0>(rs4_b, grp, vo, so); break;
+                case 1: if (p < 8) gemm_dma16_asm_q<1>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<1>(rs4_b, grp, vo, so); break;
+                case 2: if (p < 8) gemm_dma16_asm_q<2>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<2>(rs4_b, grp, vo, so); break;
+                default: if (p < 8) gemm_dma16_asm_q<3>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<3>(rs4_b, grp, vo, so); break;
+            }
+            return;
         }
         if constexpr (XT) {   // asm issue for every instantiation: invisible to hipcc's wait-count pass, counted by the schedule's own s_waitcnt
             const unsigned dst = smem_lds + (unsigned)wbase;
@@ -1817,14 +1847,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int c = i * NT + tid, row = c >> 3, phys = c & 7;
+            // (grouped M0: piece i of a wave is the 1 KB chunk 8 wave + i of the operand's LDS image -- rows 64 wave + 8 i .. + 7 -- and its source offset
+            //  is stored 1024 (i & 3) low: the instruction's immediate offset puts it back.  Rows >= 8 lie >= 8 row pitches >= 4 KB up: no underflow.)
+            const int c = M0G ? (wave * 8 + i) * 64 + lane : i * NT + tid, row = c >> 3, phys = c & 7;
             const int slot = phys ^ ((row >> 1) & 7);
             const int krow = c >> 5, c16 = c & 31;
             const int mlog = ((((c16 >> 1) ^ ((krow & 3) | (((krow >> 3) & 1) << 2))) << 1) | (c16 & 1)) * 8;
+            const uint32_t low = M0G ? (uint32_t)(i & 3) * 1024u : 0u;
             if constexpr (TA) { if (i < 2) oa[i] = ((uint32_t)krow * (uint32_t)g.lda + (uint32_t)mlog) * 2u; }
-            else oa[i] = ((uint32_t)row * (uint32_t)g.lda + (uint32_t)(slot * 8)) * 2u;
+            else oa[i] = ((uint32_t)row * (uint32_t)g.lda + (uint32_t)(slot * 8)) * 2u - low;
             if constexpr (TB) { if (i < 2) ob[i] = ((uint32_t)krow * (uint32_t)g.ldb + (uint32_t)mlog) * 2u; }
-            else ob[i] = ((uint32_t)row * (uint32_t)g.ldb + (uint32_t)(slot * 8)) * 2u;
+            else ob[i] = ((uint32_t)row * (uint32_t)g.ldb + (uint32_t)(slot * 8)) * 2u - low;
         }
     }
     for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {

@@ -16,7 +16,14 @@ __device__ __forceinline__ void dma16(u32x4_t r, unsigned lds, unsigned voff, un
     if constexpr (MODE == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
     else if constexpr (MODE == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 off, %2, %3 lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
     else if constexpr (MODE == 2) asm volatile("s_mov_b32 m0, %0\n\ts_mov_b64 exec, 1\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b64 exec, -1" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
-    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    else if constexpr (MODE == 3) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int Q>
+__device__ __forceinline__ void dma16_imm(u32x4_t r, unsigned lds, unsigned voff, unsigned soff) {
+    if constexpr (Q == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    else if constexpr (Q == 1) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    else if constexpr (Q == 2) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" : : "s"(lds), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
 // NB = accumulator blocks per wave (64: one wave per SIMD, 32: two), PIECES = DMA pieces per iteration and wave, PHASE = slot offset of the pieces
@@ -61,6 +68,12 @@ __global__ __launch_bounds__(NB == 64 ? 256 : 512) void k(const uint4* __restric
                     constexpr int NS = NA * 16;
                     if (DMA && ((slot + NS - phase) % (NS / PIECES)) == 0) {
                         const int q = (slot / (NS / PIECES)) % PIECES;
+                        if constexpr (MODE == 4) {
+                            const unsigned l4 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((it & 1) * 64 + wave * PIECES + (q & ~3)) * 1024));
+                            const unsigned s4 = __builtin_amdgcn_readfirstlane((unsigned)((wave * PIECES + (q & ~3)) * 1024) & 0xffffu);
+                            if ((q & 3) == 0) dma16_imm<0>(rs, l4, voff, s4); else if ((q & 3) == 1) dma16_imm<1>(rs, l4, voff, s4);
+                            else if ((q & 3) == 2) dma16_imm<2>(rs, l4, voff, s4); else dma16_imm<3>(rs, l4, voff, s4);
+                        } else
                         dma16<MODE>(rs, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((it & 1) * 64 + wave * PIECES + q) * 1024)), voff, __builtin_amdgcn_readfirstlane((unsigned)((wave * PIECES + q) * 1024) & 0xffffu));
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -120,6 +133,7 @@ int main(int argc, char** argv) {
             run<64, 16, true, 1>("1 wave / SIMD, 16 pieces, no VGPR address", d, ds, o, nblk, dn);
             run<64, 16, true, 2>("1 wave / SIMD, 16 pieces, one lane active", d, ds, o, nblk, dn);
             run<64, 16, true, 3>("1 wave / SIMD, 16 pieces of dword (256 B)", d, ds, o, nblk, dn);
+            run<64, 16, true, 4>("1 wave / SIMD, 16 pieces, M0 once per four", d, ds, o, nblk, dn);
             run<32, 8, false>("2 waves / SIMD, MFMAs only", d, ds, o, nblk, dn);
             run<32, 8, true>("2 waves / SIMD, 8 pieces per 64 MFMAs each", d, ds, o, nblk, dn);
         }
