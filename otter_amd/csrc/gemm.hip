@@ -40,6 +40,10 @@ __device__ unsigned long long g_gemm_timeline[2 * 4 * 8 * 8];
 #ifndef OTTER_T4_M0GROUP
 #define OTTER_T4_M0GROUP 1
 #endif
+// ... and the scalar source offsets of a K-tile computed on three free slots of the schedule (0 default; 1 = in one burst in front of the K-tile: the A/B build)
+#ifndef OTTER_T4_SETK_BURST
+#define OTTER_T4_SETK_BURST 0
+#endif
 namespace {
 
 struct GemmArgs {
@@ -1741,6 +1745,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
     // plain form: K-tiles walked from `krot_plain` on (g.korder bits 0-1, a function of the tile's index: see xt_tile) -- kt is the logical index
     int krot_plain = 0;
+    static_assert(!XT || (!TA && !TB), "the cross-tile form is built for K-contiguous operands only (its K-tile offsets come from the T4_SETK slots of KTILE_T0)");
     constexpr bool M0G = XT && !TA && !TB && (OTTER_T4_M0GROUP != 0);   // M0 written once per four pieces (gemm_dma16_asm_q)
     auto dma = [&](int bufv, int kt, int p) {
         if constexpr ((OTTER_T4_ABL & 1) != 0) { if (kt >= 2) return; }   // ablation build: no LDS-DMA inside the K loop (timing only, wrong results)
@@ -1832,6 +1837,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         sa_k = __builtin_amdgcn_readfirstlane(T.tba + (uint32_t)kp * (TA ? 4u * ksa : ksa));
         sb_k = __builtin_amdgcn_readfirstlane(T.tbb + (uint32_t)kp * (TB ? 4u * ksb : ksb));
     };
+    // round 6d: xt_setk() in three pieces, issued by the K-tile schedule itself on free slots (T4_SETK(n) in gemm_t4_ktile.inc) for the K-tile its DMA pieces
+    // are about to fetch: xs_* = the tile (xs_tile) and the logical K-tile index the K loop announced before the macro
+    uint32_t xs_tba = 0, xs_tbb = 0;
+    int xs_rot = 0, xs_kgm = 0, xs_kc = 0, xs_kt = 0, xs_x = 0, xs_kp = 0;
+    auto xs_tile = [&](const XtTile& T) { xs_tba = T.tba; xs_tbb = T.tbb; xs_rot = T.krot; xs_kgm = T.kgm; xs_kc = T.kc; };
     constexpr int XT_PARK = 2 * TILE;       // the wave's parking stripe: XPARK_BYTES each, above the ring (the whole 160 KB of LDS are in use)
     XtTile xt_cur = {}, xt_nxt = {};
     bool xt_have = false;                   // K-tiles 0 and 1 of the tile about to start were requested by the previous tile's K loop
@@ -1979,6 +1989,18 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #if (OTTER_T4_ABL & 4)   // ablation build: no workgroup barriers inside the K loop
 #define __builtin_amdgcn_s_barrier() ((void)0)
 #endif
+// the scalar source offsets of the K-tile this iteration's DMA pieces fetch, in three pieces on free slots of the schedule (cross-tile form; nothing otherwise)
+#define T4_SETK(N)                                                                                                        \
+    do {                                                                                                                  \
+        if constexpr (XT && !(OTTER_T4_SETK_BURST)) {                                                                                               \
+            if constexpr ((N) == 0) { xs_x = xs_kt + xs_rot; if (xs_x >= nk) xs_x -= nk; }                                \
+            else if constexpr ((N) == 1) xs_kp = (xs_x & ~xs_kgm) | ((xs_x + xs_kc) & xs_kgm);                            \
+            else {                                                                                                        \
+                sa_k = __builtin_amdgcn_readfirstlane(xs_tba + (uint32_t)xs_kp * (TA ? 4u * ksa : ksa));                  \
+                sb_k = __builtin_amdgcn_readfirstlane(xs_tbb + (uint32_t)xs_kp * (TB ? 4u * ksb : ksb));                  \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
 #include "gemm_t4_ktile.inc"
 #define KTILE_T0 KTILE_T0_0
 #define KTILE_X0 KTILE_X0_0
@@ -1999,22 +2021,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 // the buffers the steady state would refill anyway.  Iteration 0 is peeled for its wait: behind a full-tile tail, K-tile 1 is followed in the
 // queue by that tail's >= 32 global accesses, which the count may leave in flight (DMA == 2, see T4_WAIT_NEXT); iteration 1's wait for
 // K-tile 2 is the first that retires them.  Needs nk >= 4 (the host falls back to the plain form below that).
+// (XS_AT: announce the tile / K-tile index for the T4_SETK slots; the A/B build -DOTTER_T4_SETK_BURST=1 computes the offsets in one burst in front of the
+//  K-tile instead, as the kernel did until round 6d)
+#if OTTER_T4_SETK_BURST
+#define XS_TILE(T) ((void)0)
+#define XS_AT(T, K_) xt_setk(T, K_)
+#else
+#define XS_TILE(T) xs_tile(T)
+#define XS_AT(T, K_) (xs_kt = (K_))
+#endif
 #define KLOOP_XT(KT)                                \
     do {                                            \
-        xt_setk(xt_cur, 2);                         \
+        XS_TILE(xt_cur);                            \
+        XS_AT(xt_cur, 2);                           \
         KT(0, 0, 2, true);                          \
-        xt_setk(xt_cur, 3);                         \
+        XS_AT(xt_cur, 3);                           \
         KT(1, 1, true, true);                       \
         int t = 2;                                  \
         for (; t + 2 < nk; t += 2) {                \
-            xt_setk(xt_cur, t + 2);                 \
+            XS_AT(xt_cur, t + 2);                   \
             KT(0, t, true, true);                   \
-            xt_setk(xt_cur, t + 3);                 \
+            XS_AT(xt_cur, t + 3);                   \
             KT(1, t + 1, true, true);               \
         }                                           \
-        xt_setk(xt_nxt, 0);                         \
+        XS_TILE(xt_nxt);                            \
+        XS_AT(xt_nxt, 0);                           \
         KT(0, t, xt_pre, true);                     \
-        xt_setk(xt_nxt, 1);                         \
+        XS_AT(xt_nxt, 1);                           \
         KT(1, t + 1, xt_pre, false);                \
     } while (0)
 #ifdef OTTER_EXPERIMENTAL
@@ -2042,6 +2075,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #endif
 #undef KLOOP
 #undef KLOOP_XT
+#undef XS_TILE
+#undef XS_AT
+#undef T4_SETK
 #undef T4_WAIT_NEXT
 #undef KTILE_X0
 #undef KTILE_T0

@@ -29,7 +29,7 @@ def rd(ks, r, buf):
     return "LDF(f%s[%d][%d], %s, %s, %s, %d, %d);" % (t, ks, i, "rb" if t == "n" else "ra", "rb_hi" if t == "n" else "ra_hi", buf, ks, i)
 
 
-def schedule(name, reads, b1, dma, b2, xreads, merged=False):
+def schedule(name, reads, b1, dma, b2, xreads, merged=False, hooks=None):
     """merged: ONE barrier per K-tile -- at b1 the wave also waits for its DMA pieces of K-tile t+1 (all issued during the previous
     iteration, nothing newer in flight: vmcnt(0)); the same barrier frees the current buffer and publishes K-tile t+1; b2 is None."""
     lines, issued = [], 0
@@ -43,6 +43,8 @@ def schedule(name, reads, b1, dma, b2, xreads, merged=False):
             parts.append('asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
         elif j == b1:
             parts.append('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
+        if hooks and j in hooks:
+            parts.append("%s; SB();" % hooks[j])
         for p in dma.get(j, []):
             parts.append("if (DMA) dma(BUF, (TV) + 2, %d); SB();" % p)
             issued += 1
@@ -127,7 +129,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "inc":
     ncopies = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     print("// GENERATED by tools/gen/gemm_t4_schedule.py inc -- do not edit by hand.  KTILE_T0_<s> / KTILE_X0_<s>: s = DMA issue stagger in MFMA slots.")
     for sh in range(ncopies):
-        print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {40 + 4 * p + sh: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)}))
+        # round 6d: T4_SETK(n), n = 0..2 on the free slots 31 / 33 / 35: the cross-tile form computes the scalar source offsets of K-tile t + 2 in three
+        # pieces of <= 4 SALU instructions under MFMAs, instead of 13-19 of them in one burst between two K-tiles (a 40-70 cycle hole in the matrix pipe)
+        print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {40 + 4 * p + sh: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)},
+                       hooks={31: "T4_SETK(0)", 33: "T4_SETK(1)", 35: "T4_SETK(2)"}))
         print(schedule_split("KTILE_X0_%d" % sh, 38, dma_x(sh), 94))
     sys.exit(0)
 print(T0)
