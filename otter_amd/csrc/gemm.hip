@@ -41,6 +41,10 @@ __device__ unsigned long long g_gemm_timeline[2 * 4 * 8 * 8];
 #define OTTER_T4_M0GROUP 1
 #endif
 // ... and the scalar source offsets of a K-tile computed on three free slots of the schedule (0 default; 1 = in one burst in front of the K-tile: the A/B build)
+// ... and that M0 written one MFMA slot before the group's first piece (1 default; 0 = in the piece's own slot, with an s_nop: the A/B build)
+#ifndef OTTER_T4_M0EARLY
+#define OTTER_T4_M0EARLY 1
+#endif
 #ifndef OTTER_T4_SETK_BURST
 #define OTTER_T4_SETK_BURST 0
 #endif
@@ -1524,6 +1528,7 @@ __device__ __forceinline__ void gemm_dma16_asm(u32x4_t r, unsigned lds, uint32_t
 template <int Q>
 __device__ __forceinline__ void gemm_dma16_asm_q(u32x4_t r, unsigned lds_group, uint32_t voff_low, uint32_t soff) {
     if constexpr (Q == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    else if constexpr (Q == 4) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");   // M0 written a slot earlier
     else if constexpr (Q == 1) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
     else if constexpr (Q == 2) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
     else asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
@@ -1747,7 +1752,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     int krot_plain = 0;
     static_assert(!XT || (!TA && !TB), "the cross-tile form is built for K-contiguous operands only (its K-tile offsets come from the T4_SETK slots of KTILE_T0)");
     constexpr bool M0G = XT && !TA && !TB && (OTTER_T4_M0GROUP != 0);   // M0 written once per four pieces (gemm_dma16_asm_q)
-    auto dma = [&](int bufv, int kt, int p) {
+    // (m0_set: the schedule wrote this group's M0 one slot earlier through dma_m0() -- KTILE_T0's in-loop pieces; the prologue's calls write it themselves)
+    auto dma = [&](int bufv, int kt, int p, bool m0_set = false) {
         if constexpr ((OTTER_T4_ABL & 1) != 0) { if (kt >= 2) return; }   // ablation build: no LDS-DMA inside the K loop (timing only, wrong results)
         const int wbase = (bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16;
         if constexpr (!XT) {
@@ -1759,7 +1765,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             const uint32_t vo = p < 8 ? oa[p & 7] : ob[p & 7];
             const uint32_t so = p < 8 ? sa_k : sb_k;
             switch (p & 3) {
-                case 0: if (p < 8) gemm_dma16_asm_q<0>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<0>(rs4_b, grp, vo, so); break;
+                case 0:
+                    if (m0_set && (OTTER_T4_M0EARLY != 0)) { if (p < 8) gemm_dma16_asm_q<4>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<4>(rs4_b, grp, vo, so); }
+                    else { if (p < 8) gemm_dma16_asm_q<0>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<0>(rs4_b, grp, vo, so); }
+                    break;
                 case 1: if (p < 8) gemm_dma16_asm_q<1>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<1>(rs4_b, grp, vo, so); break;
                 case 2: if (p < 8) gemm_dma16_asm_q<2>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<2>(rs4_b, grp, vo, so); break;
                 default: if (p < 8) gemm_dma16_asm_q<3>(rs4_a, grp, vo, so); else gemm_dma16_asm_q<3>(rs4_b, grp, vo, so); break;
@@ -1790,6 +1799,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(smem + wbase), 16, (int)ob[TB ? (p & 1) : (p & 7)],
                                                      (int)((TB ? (uint32_t)(4 * kt + ((p & 7) >> 1)) : (uint32_t)kt) * ksb), 0, 0);
+        }
+    };
+    // the M0 of the group of four pieces that starts with piece p (p = 0, 4, 8, 12), written by the schedule one MFMA slot before that piece: the
+    // s_mov's latency then hides under the MFMA instead of standing in front of the buffer_load (tools/probe/dma_issue.hip: -40 cycles per K-tile)
+    auto dma_m0 = [&](int bufv, int p) {
+        if constexpr ((OTTER_T4_ABL & 1) != 0) return;
+        if constexpr (XT && M0G && (OTTER_T4_M0EARLY != 0)) {
+            const unsigned grp = smem_lds + (unsigned)((bufv & 1) * TILE + (p >> 3) * (BM * 128) + (wave * 8 + (p & 4)) * 1024);
+            asm volatile("s_mov_b32 m0, %0" : : "s"(grp) : "memory");
         }
     };
     // ---- T4_XT_* : the cross-tile form (XT, round 6) --------------------------------------------------------------------------------

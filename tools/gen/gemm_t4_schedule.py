@@ -45,8 +45,11 @@ def schedule(name, reads, b1, dma, b2, xreads, merged=False, hooks=None):
             parts.append('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
         if hooks and j in hooks:
             parts.append("%s; SB();" % hooks[j])
+        for p in dma.get(j + 1, []):
+            if hooks and p % 4 == 0:   # (round 6d) M0 of a group of four pieces is written ONE SLOT before its first piece: the s_mov's latency hides under an MFMA
+                parts.append("if (DMA) dma_m0(BUF, %d); SB();" % p)
         for p in dma.get(j, []):
-            parts.append("if (DMA) dma(BUF, (TV) + 2, %d); SB();" % p)
+            parts.append("if (DMA) dma(BUF, (TV) + 2, %d%s); SB();" % (p, ", true" if hooks else ""))
             issued += 1
         if b2 is not None and j == b2:
             parts.append("if (NEXT) { T4_WAIT_NEXT(DMA, %d); __builtin_amdgcn_s_barrier(); } SB();" % issued)
