@@ -1525,13 +1525,16 @@ __device__ __forceinline__ void gemm_dma16_asm(u32x4_t r, unsigned lds, uint32_t
 // global address: the per-lane source offset of piece q is stored 1024 q low.  tools/probe/dma_issue.hip: an `s_mov m0 + s_nop` pair beside
 // back-to-back MFMAs costs ~12 cycles of matrix pipe; 12 of the 16 pairs of a K-tile go (profiles/r06d_dma_issue_probe.txt: +6 % MFMA rate on zeros,
 // +3-4 % on random operands).  Nothing else in these kernels touches M0 (checked in the object code: 128 s_mov m0 = 128 LDS-DMA instructions).
+#ifndef OTTER_T4_DMA_AUX   // cache-policy bits of the operand loads (A/B builds: " nt", " sc1", " sc0 sc1"); default: none
+#define OTTER_T4_DMA_AUX ""
+#endif
 template <int Q>
 __device__ __forceinline__ void gemm_dma16_asm_q(u32x4_t r, unsigned lds_group, uint32_t voff_low, uint32_t soff) {
-    if constexpr (Q == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
-    else if constexpr (Q == 4) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");   // M0 written a slot earlier
-    else if constexpr (Q == 1) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
-    else if constexpr (Q == 2) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
-    else asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    if constexpr (Q == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" OTTER_T4_DMA_AUX " lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    else if constexpr (Q == 4) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen" OTTER_T4_DMA_AUX " lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");   // M0 written a slot earlier
+    else if constexpr (Q == 1) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:1024" OTTER_T4_DMA_AUX " lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    else if constexpr (Q == 2) asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:2048" OTTER_T4_DMA_AUX " lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
+    else asm volatile("buffer_load_dwordx4 %1, %2, %3 offen offset:3072" OTTER_T4_DMA_AUX " lds" : : "s"(lds_group), "v"(voff_low), "s"(r), "s"(soff) : "memory");
 }
 
 // Address of a transpose read: k-row, half row, swizzled block and the lane's 8 bytes occupy DISJOINT bit fields of the LDS
