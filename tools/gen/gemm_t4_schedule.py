@@ -134,8 +134,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "inc":
     for sh in range(ncopies):
         # round 6d: T4_SETK(n), n = 0..2 on the free slots 31 / 33 / 35: the cross-tile form computes the scalar source offsets of K-tile t + 2 in three
         # pieces of <= 4 SALU instructions under MFMAs, instead of 13-19 of them in one burst between two K-tiles (a 40-70 cycle hole in the matrix pipe)
-        print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {40 + 4 * p + sh: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)},
-                       hooks={31: "T4_SETK(0)", 33: "T4_SETK(1)", 35: "T4_SETK(2)"}))
+        import os
+        dstep = int(os.environ.get("T4_DMA_STEP", "4").rstrip("e"))    # A/B: MFMA slots between two DMA pieces (4 = the product schedule: slots 40, 44 .. 100)
+        if os.environ.get("T4_EARLY_B1") == "1":           # A/B: k-step-1 reads on every slot 0..15, barrier #1 at slot 20, pieces every 6th slot 22 .. 112
+            print(schedule("KTILE_T0_%d" % sh, {r: [r] for r in range(16)}, 20, {22 + 6 * p + sh: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)},
+                           hooks={16: "T4_SETK(0)", 17: "T4_SETK(1)", 18: "T4_SETK(2)"}))
+        elif os.environ.get("T4_DMA_STEP", "5e") == "5e":    # THE PRODUCT SCHEDULE since round 6d: pieces 0-10 every 5th slot 40 .. 90, pieces 11-15 on the even slots
+                                                             # 96 .. 112 (the odd ones carry the reads).  Until then: every 4th slot 40 .. 100 (T4_DMA_STEP=4).  Measured on cold
+                                                             # operands (profiles/r06d_dma_step_ab.txt): every 2nd slot +7 %, every 3rd +2.5 %, every 5th -0.5 ... -2 % against every 4th
+            print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {(40 + 5 * p if p < 11 else 96 + 4 * (p - 11)) + sh: [p] for p in range(16)}, 94,
+                           {97 + 2 * r: [r] for r in range(16)}, hooks={31: "T4_SETK(0)", 33: "T4_SETK(1)", 35: "T4_SETK(2)"}))
+        else:
+            print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {40 + dstep * p + sh: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)},
+                           hooks={31: "T4_SETK(0)", 33: "T4_SETK(1)", 35: "T4_SETK(2)"}))
         print(schedule_split("KTILE_X0_%d" % sh, 38, dma_x(sh), 94))
     sys.exit(0)
 print(T0)
