@@ -112,6 +112,12 @@ def schedule_split(name, b1, dma, b2):
 
 
 def dma_x(shift):
+    import os
+    if os.environ.get("T4_X_SPREAD") == "1":     # A/B (round 6d): the K-major schedule's pieces as far apart as the K-contiguous one's: 12 on slots 40 .. 89 (steps 4 / 5), 4 behind barrier #2
+        sl = [40, 44, 49, 53, 58, 62, 67, 71, 76, 80, 85, 89, 98, 104, 110, 116]
+        return {x + shift: [i] for i, x in enumerate(sl)}
+    if os.environ.get("T4_X_SPREAD") == "2":     # ... or all 16 in front of barrier #2, evenly: 40 .. 92 is what there is (steps 3 / 4): the product schedule
+        pass
     d, slot = {}, 40 + shift
     for p_ in range(16):
         d[slot] = [p_]
