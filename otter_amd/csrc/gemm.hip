@@ -1789,6 +1789,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         // rides in the scalar offset (the register file of this kernel is full: 256 accumulators + 128 fragment registers)
         if constexpr ((TA || TB) && !(OTTER_KMDBG & 2)) {   // asm issue for BOTH operands of a K-major instantiation (see gemm_dma16_asm)
             const unsigned dst = smem_lds + (unsigned)wbase;
+            if (m0_set) {   // (KTILE_X0 since round 6d: dma_m0x() wrote this piece's M0 one slot earlier; the prologue's calls write it themselves)
+                if (p < 8) {
+                    if constexpr (TA) gemm_dma16_asm_q<4>(rs4_a, dst, oa[p & 1], (uint32_t)(4 * kt + ((p & 7) >> 1)) * ksa);
+                    else gemm_dma16_asm_q<4>(rs4_a, dst, oa[p & 7], (uint32_t)kt * ksa);
+                } else {
+                    if constexpr (TB) gemm_dma16_asm_q<4>(rs4_b, dst, ob[p & 1], (uint32_t)(4 * kt + ((p & 7) >> 1)) * ksb);
+                    else gemm_dma16_asm_q<4>(rs4_b, dst, ob[p & 7], (uint32_t)kt * ksb);
+                }
+            } else
             if (p < 8) {
                 if constexpr (TA) gemm_dma16_asm(rs4_a, dst, oa[p & 1], (uint32_t)(4 * kt + ((p & 7) >> 1)) * ksa);   // (OTTER_KMDBG: debug builds)
                 else gemm_dma16_asm(rs4_a, dst, oa[p & 7], (uint32_t)kt * ksa);
@@ -1806,6 +1815,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     };
     // the M0 of the group of four pieces that starts with piece p (p = 0, 4, 8, 12), written by the schedule one MFMA slot before that piece: the
     // s_mov's latency then hides under the MFMA instead of standing in front of the buffer_load (tools/probe/dma_issue.hip: -40 cycles per K-tile)
+    auto dma_m0x = [&](int bufv, int p) {   // K-major schedule (KTILE_X0): the M0 of piece p, one MFMA slot before the piece
+        if constexpr ((TA || TB) && !(OTTER_KMDBG & 2)) {
+            const unsigned dst = smem_lds + (unsigned)((bufv & 1) * TILE + (p >> 3) * (BM * 128) + ((p & 7) * NT + wave * 64) * 16);
+            asm volatile("s_mov_b32 m0, %0" : : "s"(dst) : "memory");
+        }
+    };
     auto dma_m0 = [&](int bufv, int p) {
         if constexpr ((OTTER_T4_ABL & 1) != 0) return;
         if constexpr (XT && M0G && (OTTER_T4_M0EARLY != 0)) {

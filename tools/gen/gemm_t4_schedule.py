@@ -94,8 +94,13 @@ def schedule_split(name, b1, dma, b2):
             parts.append(rd2("AB"[j & 1], 1, j >> 1, "BUF") + " SB();")
         if j == b1:
             parts.append('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
+        import os
+        early = os.environ.get("T4_X_M0EARLY", "1") == "1"     # round 6d (product): every piece's M0 written one slot before the piece (no s_nop, the s_mov's latency under an MFMA): -0.5 ... -1 %
+        if early:
+            for p in dma.get(j + 1, []):
+                parts.append("if (DMA) dma_m0x(BUF, %d); SB();" % p)
         for p in dma.get(j, []):
-            parts.append("if (DMA) dma(BUF, (TV) + 2, %d); SB();" % p)
+            parts.append("if (DMA) dma(BUF, (TV) + 2, %d%s); SB();" % (p, ", true" if early else ""))
             issued += 1
         if j == b2:
             parts.append("if (NEXT) { T4_WAIT_NEXT(DMA, %d); __builtin_amdgcn_s_barrier(); } SB();" % issued)
