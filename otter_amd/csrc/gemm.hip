@@ -1753,6 +1753,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     // piece p (0..7 = A, 8..15 = B) of K-tile kt into buffer BUFV
     // plain form: K-tiles walked from `krot_plain` on (g.korder bits 0-1, a function of the tile's index: see xt_tile) -- kt is the logical index
     int krot_plain = 0;
+    int kx_t = 0;                 // K-major schedule: wrapped index and scalar source offsets of the K-tile in flight (T4_SETKX)
+    uint32_t kx_a = 0, kx_b = 0;
     static_assert(!XT || (!TA && !TB), "the cross-tile form is built for K-contiguous operands only (its K-tile offsets come from the T4_SETK slots of KTILE_T0)");
     constexpr bool M0G = XT && !TA && !TB && (OTTER_T4_M0GROUP != 0);   // M0 written once per four pieces (gemm_dma16_asm_q)
     // (m0_set: the schedule wrote this group's M0 one slot earlier through dma_m0() -- KTILE_T0's in-loop pieces; the prologue's calls write it themselves)
@@ -1789,13 +1791,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         // rides in the scalar offset (the register file of this kernel is full: 256 accumulators + 128 fragment registers)
         if constexpr ((TA || TB) && !(OTTER_KMDBG & 2)) {   // asm issue for BOTH operands of a K-major instantiation (see gemm_dma16_asm)
             const unsigned dst = smem_lds + (unsigned)wbase;
-            if (m0_set) {   // (KTILE_X0 since round 6d: dma_m0x() wrote this piece's M0 one slot earlier; the prologue's calls write it themselves)
+            if (m0_set) {   // (KTILE_X0 since round 6d: dma_m0x() wrote this piece's M0 one slot earlier and T4_SETKX the K-tile's scalar offsets; the
+                            //  prologue's calls do both themselves)
                 if (p < 8) {
-                    if constexpr (TA) gemm_dma16_asm_q<4>(rs4_a, dst, oa[p & 1], (uint32_t)(4 * kt + ((p & 7) >> 1)) * ksa);
-                    else gemm_dma16_asm_q<4>(rs4_a, dst, oa[p & 7], (uint32_t)kt * ksa);
+                    if constexpr (TA) gemm_dma16_asm_q<4>(rs4_a, dst, oa[p & 1], kx_a + (uint32_t)((p & 7) >> 1) * ksa);
+                    else gemm_dma16_asm_q<4>(rs4_a, dst, oa[p & 7], kx_a);
                 } else {
-                    if constexpr (TB) gemm_dma16_asm_q<4>(rs4_b, dst, ob[p & 1], (uint32_t)(4 * kt + ((p & 7) >> 1)) * ksb);
-                    else gemm_dma16_asm_q<4>(rs4_b, dst, ob[p & 7], (uint32_t)kt * ksb);
+                    if constexpr (TB) gemm_dma16_asm_q<4>(rs4_b, dst, ob[p & 1], kx_b + (uint32_t)((p & 7) >> 1) * ksb);
+                    else gemm_dma16_asm_q<4>(rs4_b, dst, ob[p & 7], kx_b);
                 }
             } else
             if (p < 8) {
@@ -2037,6 +2040,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             }                                                                                                             \
         }                                                                                                                 \
     } while (0)
+// K-major schedule (KTILE_X0, plain form): the wrapped K-tile index and the two operands' scalar source offsets of the K-tile whose pieces follow
+#define T4_SETKX(N, KT_)                                                                                                  \
+    do {                                                                                                                  \
+        if constexpr (!XT && (TA || TB)) {                                                                                \
+            if constexpr ((N) == 0) { kx_t = (KT_) + krot_plain; if (kx_t >= nk) kx_t -= nk; }                            \
+            else {                                                                                                        \
+                kx_a = __builtin_amdgcn_readfirstlane((uint32_t)kx_t * (TA ? 4u * ksa : ksa));                            \
+                kx_b = __builtin_amdgcn_readfirstlane((uint32_t)kx_t * (TB ? 4u * ksb : ksb));                            \
+            }                                                                                                             \
+        }                                                                                                                 \
+    } while (0)
 #include "gemm_t4_ktile.inc"
 #define KTILE_T0 KTILE_T0_0
 #define KTILE_X0 KTILE_X0_0
@@ -2111,6 +2125,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #endif
 #undef KLOOP
 #undef KLOOP_XT
+#undef T4_SETKX
 #undef XS_TILE
 #undef XS_AT
 #undef T4_SETK

@@ -94,6 +94,8 @@ def schedule_split(name, b1, dma, b2):
             parts.append(rd2("AB"[j & 1], 1, j >> 1, "BUF") + " SB();")
         if j == b1:
             parts.append('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); SB();')
+        if j in (33, 35):   # (round 6d) the scalar source offsets of K-tile t + 2 on two free slots instead of a burst in front of its first piece
+            parts.append("T4_SETKX(%d, (TV) + 2); SB();" % (0 if j == 33 else 1))
         import os
         early = os.environ.get("T4_X_M0EARLY", "1") == "1"     # round 6d (product): every piece's M0 written one slot before the piece (no s_nop, the s_mov's latency under an MFMA): -0.5 ... -1 %
         if early:
