@@ -1972,7 +1972,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         // accumulators in explicit AGPRs (asm MFMAs): the K-major instantiations and EVERY cross-tile instantiation (with the builtin MFMA
         // hipcc re-homes accumulator blocks around the restructured tile loop: hundreds of v_accvgpr_mov at the K loop's entry, spills)
         constexpr bool XACC = (TA || TB || XT) && !(OTTER_KMDBG & 1);
-        if constexpr (XACC) {
+        if constexpr (XACC && XT) {
+            // nothing: the first K-tile's k-step 0 runs with C = 0 (MMAZ in KTILE_T0F)
+        } else if constexpr (XACC) {
             ACC_ZERO_ROW(0); ACC_ZERO_ROW(1); ACC_ZERO_ROW(2); ACC_ZERO_ROW(3); ACC_ZERO_ROW(4); ACC_ZERO_ROW(5); ACC_ZERO_ROW(6); ACC_ZERO_ROW(7);
         } else {
 #pragma unroll
@@ -2011,6 +2013,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
             asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]"                                                  \
                          : : "v"(fn[KS][NI]), "v"(fm[KS][MI]), "n"(((MI) * 8 + (NI)) * 4), "n"(((MI) * 8 + (NI)) * 4 + 3) : AC_##MI##_##NI); \
         else acc[MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[KS][NI], fm[KS][MI], acc[MI][NI], 0, 0, 0);                  \
+    } while (0)
+// k-step 0 of a tile's FIRST K-tile in the cross-tile form (KTILE_T0F): C = 0, the accumulators are not zeroed beforehand
+#define MMAZ(KS, MI, NI)                                                                                                            \
+    do {                                                                                                                          \
+        if constexpr (XACC && XT)                                                                                                  \
+            asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, 0"                                                           \
+                         : : "v"(fn[KS][NI]), "v"(fm[KS][MI]), "n"(((MI) * 8 + (NI)) * 4), "n"(((MI) * 8 + (NI)) * 4 + 3) : AC_##MI##_##NI); \
+        else MMA(KS, MI, NI);                                                                                                      \
     } while (0)
 // the wait for K-tile t + 1 in front of barrier #2: N pieces of K-tile t + 2 have been issued behind it (DMA), none (!DMA), or -- the first
 // iteration of a cross-tile tile (DMA == 2) -- N pieces plus the previous tile's tail, of which xt_slack operations may stay in flight
@@ -2053,6 +2063,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
     } while (0)
 #include "gemm_t4_ktile.inc"
 #define KTILE_T0 KTILE_T0_0
+#define KTILE_T0F KTILE_T0F_0
 #define KTILE_X0 KTILE_X0_0
 #ifdef OTTER_EXPERIMENTAL  // tools-only: variants 27-29: alternative slot placements T1-T3 of variant 26's K-tile schedule (generated by tools/gen/gemm_t4_schedule.py)
 #include "experimental/gemm_t4_placements_t1_t3.inc"
@@ -2080,11 +2091,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #define XS_TILE(T) xs_tile(T)
 #define XS_AT(T, K_) (xs_kt = (K_))
 #endif
-#define KLOOP_XT(KT)                                \
+#define KLOOP_XT(KT, KTF)                           \
     do {                                            \
         XS_TILE(xt_cur);                            \
         XS_AT(xt_cur, 2);                           \
-        KT(0, 0, 2, true);                          \
+        KTF(0, 0, 2, true);                         \
         XS_AT(xt_cur, 3);                           \
         KT(1, 1, true, true);                       \
         int t = 2;                                  \
@@ -2103,8 +2114,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #ifdef OTTER_EXPERIMENTAL
         static_assert(!XT || SCH == 0, "the cross-tile form runs the default placement only");
         if constexpr (XT) {
-            if constexpr (TA || TB) KLOOP_XT(KTILE_X0);
-            else KLOOP_XT(KTILE_T0);
+            if constexpr (TA || TB) KLOOP_XT(KTILE_X0, KTILE_X0);
+            else KLOOP_XT(KTILE_T0, KTILE_T0F);
         } else if constexpr (SCH == 0) KLOOP(KTILE_T0);
         else if constexpr (SCH == 1) KLOOP(KTILE_T1);
         else if constexpr (SCH == 2) KLOOP(KTILE_T2);
@@ -2115,8 +2126,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #else
         static_assert(SCH == 0, "the alternative placements of variant 26 (27-29) are in the OTTER_EXPERIMENTAL build only");
         if constexpr (XT) {
-            if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP_XT(KTILE_X0);
-            else KLOOP_XT(KTILE_T0);
+            if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP_XT(KTILE_X0, KTILE_X0);
+            else KLOOP_XT(KTILE_T0, KTILE_T0F);
         } else if constexpr ((TA || TB) && !(OTTER_KMDBG & 4)) KLOOP(KTILE_X0);
         else KLOOP(KTILE_T0);
 #endif
@@ -2132,6 +2143,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
 #undef T4_WAIT_NEXT
 #undef KTILE_X0
 #undef KTILE_T0
+#undef KTILE_T0F
+#undef KTILE_T0F_0
+#undef MMAZ
 #undef KTILE_T0_0
 #undef KTILE_X0_0
 #undef MMA

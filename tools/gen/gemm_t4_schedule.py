@@ -29,14 +29,14 @@ def rd(ks, r, buf):
     return "LDF(f%s[%d][%d], %s, %s, %s, %d, %d);" % (t, ks, i, "rb" if t == "n" else "ra", "rb_hi" if t == "n" else "ra_hi", buf, ks, i)
 
 
-def schedule(name, reads, b1, dma, b2, xreads, merged=False, hooks=None):
+def schedule(name, reads, b1, dma, b2, xreads, merged=False, hooks=None, zero_first=False):
     """merged: ONE barrier per K-tile -- at b1 the wave also waits for its DMA pieces of K-tile t+1 (all issued during the previous
     iteration, nothing newer in flight: vmcnt(0)); the same barrier frees the current buffer and publishes K-tile t+1; b2 is None."""
     lines, issued = [], 0
     for j in range(128):
         ks, q = j >> 6, j & 63
         mi, ni = ORD[q]
-        parts = ["MMA(%d, %d, %d); SB();" % (ks, mi, ni)]
+        parts = ["%s(%d, %d, %d); SB();" % ("MMAZ" if (zero_first and ks == 0) else "MMA", ks, mi, ni)]
         for r in reads.get(j, []):
             parts.append(rd(1, r, "BUF") + " SB();")
         if j == b1 and merged:
@@ -157,6 +157,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "inc":
                                                              # operands (profiles/r06d_dma_step_ab.txt): every 2nd slot +7 %, every 3rd +2.5 %, every 5th -0.5 ... -2 % against every 4th
             print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {(40 + 5 * p if p < 11 else 96 + 4 * (p - 11)) + sh: [p] for p in range(16)}, 94,
                            {97 + 2 * r: [r] for r in range(16)}, hooks={31: "T4_SETK(0)", 33: "T4_SETK(1)", 35: "T4_SETK(2)"}))
+            # the same K-tile as the FIRST of a tile in the cross-tile form (its peeled iteration 0): the 64 MFMAs of k-step 0 take a zero C operand (MMAZ),
+            # so the 256 v_accvgpr_write that zeroed the accumulators between two tiles (~1.2 k cycles with the matrix pipe idle) are gone
+            print(schedule("KTILE_T0F_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {(40 + 5 * p if p < 11 else 96 + 4 * (p - 11)) + sh: [p] for p in range(16)}, 94,
+                           {97 + 2 * r: [r] for r in range(16)}, hooks={31: "T4_SETK(0)", 33: "T4_SETK(1)", 35: "T4_SETK(2)"}, zero_first=True))
         else:
             print(schedule("KTILE_T0_%d" % sh, {2 * r: [r] for r in range(16)}, 38, {40 + dstep * p + sh: [p] for p in range(16)}, 94, {97 + 2 * r: [r] for r in range(16)},
                            hooks={31: "T4_SETK(0)", 33: "T4_SETK(1)", 35: "T4_SETK(2)"}))
