@@ -897,6 +897,8 @@ def main():
                        "rccl_algo": (args.rccl_algo or os.environ.get("NCCL_ALGO")) if use_dist else None,
                        "rccl_max_channels": (args.rccl_max_channels or os.environ.get("NCCL_MAX_NCHANNELS")) if use_dist else None,
                        "gemm_grid": "per-tile" if step.grid_mode == 2 else "persistent",
+                       # which GEMMs of the frozen decoder run on csrc/gemm.hip (otter_amd/mpt.py _own_mode): "1t" = all of them (default since round 6d)
+                       "decoder_gemm": os.environ.get("OTTER_OWN_DECODER_GEMM", "1t") if args.config == "c2" else None,
                        # clip_grad_norm_'s reduction: "fused:<n>" = n weight gradients took sum(dW^2) from their own GEMM launch (single rank),
                        # the rest from the sweep; "sweep" = every gradient (OTTER_NO_FUSED_GRAD_NORM=1, or a DP reducer is attached)
                        "grad_norm": ("fused:%d" % step.optimizer.fused_norm_tensors) if getattr(step, "norm_sink", None) is not None else "sweep"},

@@ -107,15 +107,19 @@ class _Norm(nn.LayerNorm):
 
 def _own_mode() -> str:
     """Which GEMMs of the frozen decoder run on csrc/gemm.hip, OTTER_OWN_DECODER_GEMM:
-      "mlp" (the default since round 6): the two products of the frozen MLP that carry a fusion -- up_proj + GELU, down_proj's input gradient
+      "1t" (THE DEFAULT since round 6d): EVERY decoder GEMM on the own kernels -- Wqkv, out_proj, up_proj + GELU, down_proj forward; the four input
+            gradients against stored transposed copies of the frozen weights (K-contiguous operands, the cross-tile form of variant 26), down_proj's with
+            GELU' in the tail.  Same-box interleaved A/B on the round-6d kernels: 123.17 / 123.45 ms per step against 123.42 / 123.74 for "mlp" and
+            124.5 for "1" (profiles/r06d_modes_ab_final_box*.txt) -- own <= library in the step for the first time; it was +1.0 % in round 6b, +4.0 % in round 5.
+      "mlp" (the default of rounds 6-6c): the two products of the frozen MLP that carry a fusion -- up_proj + GELU, down_proj's input gradient
             + GELU' (functional.FrozenMLPFusedLegsFn) -- so that the decoder's 64 stand-alone GELU / GELU' passes per step (3.4 ms) are gone;
             the plain products stay on hipBLASLt.  Same-box interleaved A/B, round 6 (cross-tile ring + K-tile rotation in variant 26):
             126.33 ms per step against 126.73 with the library for all of them (profiles/r06_own_decoder_ab.txt); it was +2.8 % in round 5.
       "1":  EVERY decoder GEMM on the own kernels (functional.FrozenMLPFn, input gradients against the weights as stored through the K-major
             kernel: no transposed copies, 13 GB less): +1.2 % on the step (round 5: +4.0 %) -- the library's plain products are still ahead in situ.
       "0" / "lib": hipBLASLt for all of them + stand-alone GELU kernels (the round 1-5 default; A/B switch)."""
-    v = os.environ.get("OTTER_OWN_DECODER_GEMM", "mlp").lower()
-    return {"1": "all", "1t": "allt", "mlp": "mlp", "": "mlp", "attn": "attn", "attn_qkv": "attn_qkv", "attn_out": "attn_out"}.get(v, "lib")
+    v = os.environ.get("OTTER_OWN_DECODER_GEMM", "1t").lower()
+    return {"1": "all", "1t": "allt", "mlp": "mlp", "": "allt", "attn": "attn", "attn_qkv": "attn_qkv", "attn_out": "attn_out"}.get(v, "lib")
 
 
 def _own_gemm() -> bool:
