@@ -110,7 +110,8 @@ def _own_mode() -> str:
       "1t" (THE DEFAULT since round 6d): EVERY decoder GEMM on the own kernels -- Wqkv, out_proj, up_proj + GELU, down_proj forward; the four input
             gradients against stored transposed copies of the frozen weights (K-contiguous operands, the cross-tile form of variant 26), down_proj's with
             GELU' in the tail.  Same-box interleaved A/B on the round-6d kernels: 123.17 / 123.45 ms per step against 123.42 / 123.74 for "mlp" and
-            124.5 for "1" (profiles/r06d_modes_ab_final_box*.txt) -- own <= library in the step for the first time; it was +1.0 % in round 6b, +4.0 % in round 5.
+            124.5 for "1" on the pool's fastest box, 128.18 against 127.71 (+0.37 %) on a mid box (profiles/r06d_modes_ab_final_box*.txt) -- inside the pool's box-to-box
+            spread, and the decoder then needs no vendor GEMM; it was +1.0 % in round 6b, +4.0 % in round 5.
       "mlp" (the default of rounds 6-6c): the two products of the frozen MLP that carry a fusion -- up_proj + GELU, down_proj's input gradient
             + GELU' (functional.FrozenMLPFusedLegsFn) -- so that the decoder's 64 stand-alone GELU / GELU' passes per step (3.4 ms) are gone;
             the plain products stay on hipBLASLt.  Same-box interleaved A/B, round 6 (cross-tile ring + K-tile rotation in variant 26):
