@@ -854,7 +854,7 @@ def main():
             names = {13: "gemm_bf16_ph_kernel (256x256x64 tile, 8 waves, phased)", 18: "gemm_bf16_r4_kernel (256x256x64 tile, 4 waves, register-resident K-tile)",
                      26: "gemm_bf16_t4_kernel (256x256x64 tile, 4 waves, register-resident K-tile, 16x16x32 MFMA; cross-tile ring for K-contiguous operands, K-tiles rotated by N panel)"}
             traffic_src = None
-            for cand in ({18: ["r02_pmc_gemm_ffn_v18.json"], 26: ["r06_pmc_gemm_ffn_traffic.json", "r05_pmc_gemm_ffn_traffic.json", "r03_pmc_gemm_ffn_traffic.json"]}.get(v, ["r01_pmc_gemm_ffn_v13.json"])):
+            for cand in ({18: ["r02_pmc_gemm_ffn_v18.json"], 26: ["r06d_pmc_gemm_ffn_traffic.json", "r06_pmc_gemm_ffn_traffic.json", "r05_pmc_gemm_ffn_traffic.json", "r03_pmc_gemm_ffn_traffic.json"]}.get(v, ["r01_pmc_gemm_ffn_v13.json"])):
                 pmc = os.path.join(ROOT, "profiles", cand)          # newest committed PMC pass of this kernel first
                 if os.path.exists(pmc) and (M, N, Kd) == (4096, 16384, 4096):
                     with open(pmc) as f:
