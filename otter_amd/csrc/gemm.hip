@@ -1910,9 +1910,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
         }
     }
     for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-        int tile_m, tile_n;
-        tile_of_block(g, vb, tile_m, tile_n);
-        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+        int tile_m = 0, tile_n = 0;
+        if constexpr (XT) {
+            // (round 6d) the tile the previous iteration prefetched for IS this one: its XtTile (tile mapping = three integer divisions, K rotation) is reused
+            if (xt_have) xt_cur = xt_nxt;
+            else xt_cur = xt_tile(vb);
+        } else tile_of_block(g, vb, tile_m, tile_n);
+        const int64_t m0 = XT ? xt_cur.m0 : (int64_t)tile_m * BM, n0 = XT ? xt_cur.n0 : (int64_t)tile_n * BN;
         TMARK(0);
         const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N) && !(g.dbg & 16) && (g.cdt == OTTER_F32 || g.wide);
         // XT: this tile's K loop requests the next tile's first two K-tiles when there is one and when its own tail leaves the ring alone
@@ -1924,7 +1928,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_t4_kernel(GemmArgs g) {
                                                         : (rotm == 2 ? (xcd * nk) >> 3 : (rotm == 3 ? ((tile_n >> 2) & 3) * (nk >> 2) : 0)));
         }
         if constexpr (XT) {
-            xt_cur = xt_tile(vb);
             xt_pre = full && (vb + (int)gridDim.x < ntiles);
             xt_nxt = xt_pre ? xt_tile(vb + (int)gridDim.x) : xt_cur;
         }
